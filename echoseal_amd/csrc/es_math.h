@@ -1,0 +1,223 @@
+/* es_math.h -- float64 exp / log1p / logaddexp with a FIXED operation order.
+ *
+ * Why this exists.  The reference's SCL decoder (rtwm/fastpolar.py:18-23, 32-40) computes
+ *     f(a,b)      = np.logaddexp(a,b) - np.logaddexp(0.0, a+b)
+ *     penalty(l)  = np.log1p(np.exp(-abs(l)))
+ * in float64.  NumPy's logaddexp inner loop is  max + log1p(exp(-|x-y|))  evaluated with the
+ * C library's scalar exp()/log1p(), i.e. on Linux/x86-64 with glibc (>= 2.28):
+ *     exp   : the table-driven algorithm of Arm's optimized-routines (N = 128, degree-5
+ *             polynomial), built with FMA contraction on FMA-capable CPUs,
+ *     log1p : the classic fdlibm algorithm with glibc's split Horner scheme, no FMA.
+ * Path metrics are compared with exact float64 ordering, so a last-bit difference in exp/log1p can
+ * flip a sort.  The device math library does not promise those exact roundings, so the kernel and
+ * the CPU oracle both use THIS restatement, which fixes every rounding step (explicit fma where
+ * glibc's FMA build fuses, separate mul/add elsewhere; compile with -ffp-contract=off).
+ * tests/test_oracle_math.py checks it bit-for-bit against the host libm on millions of inputs.
+ *
+ * The same file is compiled by gcc (oracle, host tests) and by hipcc for gfx950 (kernels).
+ */
+#ifndef ES_MATH_H
+#define ES_MATH_H
+
+#include <stdint.h>
+#include "es_exp_tab.h"
+
+#if defined(__HIPCC__)
+#define ES_HD __host__ __device__ __forceinline__
+#else
+#define ES_HD static inline
+#endif
+
+#define ES_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+ES_HD uint64_t es_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+ES_HD double   es_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+ES_HD int32_t  es_hi32(double x) { return (int32_t)(es_d2u(x) >> 32); }
+
+/* ---- exp ------------------------------------------------------------------------------- */
+#define ES_EXP_INVLN2N   0x1.71547652b82fep+7     /* 128/ln2            */
+#define ES_EXP_SHIFT     0x1.8p+52
+#define ES_EXP_NLN2HI    (-0x1.62e42fefa0000p-8)  /* -ln2/128, high part */
+#define ES_EXP_NLN2LO    (-0x1.cf79abc9e3b3ap-47) /* -ln2/128, low part  */
+#define ES_EXP_C2        0x1.ffffffffffdbdp-2
+#define ES_EXP_C3        0x1.555555555543cp-3
+#define ES_EXP_C4        0x1.55555cf172b91p-5
+#define ES_EXP_C5        0x1.1111167a4d017p-7
+
+/* exp(x) for any finite or infinite x <= 0 and for 0 <= x < 512 (the decoder only ever passes
+ * x = -|t|).  `tab` is the 256-word table of es_exp_tab.h (LDS copy on the device).           */
+ES_HD double es_exp(double x, const uint64_t* tab)
+{
+    const uint64_t xb = es_d2u(x);
+    uint32_t abstop = (uint32_t)(xb >> 52) & 0x7ffu;
+    int special = 0;
+    if (abstop - 0x3c9u >= 0x3fu) {
+        if ((int32_t)(abstop - 0x3c9u) < 0)
+            return 1.0 + x;                          /* |x| < 2^-54 (also +-0) */
+        if (abstop >= 0x409u) {                      /* |x| >= 1024, inf, nan  */
+            if (xb == 0xfff0000000000000ULL) return 0.0;
+            if (abstop >= 0x7ffu) return 1.0 + x;    /* nan, +inf */
+            return (xb >> 63) ? 0.0 : es_u2d(0x7ff0000000000000ULL);
+        }
+        special = 1;                                 /* 512 <= |x| < 1024 */
+    }
+    /* x = k*ln2/128 + r */
+    double kd = ES_FMA(x, ES_EXP_INVLN2N, ES_EXP_SHIFT);
+    const uint64_t ki = es_d2u(kd);
+    kd = kd - ES_EXP_SHIFT;
+    double r = ES_FMA(kd, ES_EXP_NLN2HI, x);
+    r = ES_FMA(kd, ES_EXP_NLN2LO, r);
+    const uint32_t idx = 2u * (uint32_t)(ki & 127u);
+    const uint64_t top = ki << 45;
+    const double tail = es_u2d(tab[idx]);
+    uint64_t sbits = tab[idx + 1] + top;
+    const double p23 = ES_FMA(r, ES_EXP_C3, ES_EXP_C2);
+    const double tr = r + tail;
+    const double r2 = r * r;
+    const double p45 = ES_FMA(r, ES_EXP_C5, ES_EXP_C4);
+    const double t = ES_FMA(p23, r2, tr);
+    const double r4 = r2 * r2;
+    const double tmp = ES_FMA(r4, p45, t);
+    if (!special) {
+        const double scale = es_u2d(sbits);
+        return ES_FMA(scale, tmp, scale);
+    }
+    if ((ki & 0x80000000ULL) == 0) {                 /* k > 0: not reached for x <= 0 */
+        sbits -= 1009ULL << 52;
+        const double scale = es_u2d(sbits);
+        return 0x1p1009 * ES_FMA(scale, tmp, scale);
+    }
+    /* k < 0: result may be subnormal; round once */
+    sbits += 1022ULL << 52;
+    const double scale = es_u2d(sbits);
+    const double st = scale * tmp;
+    double y = scale + st;
+    if (y < 1.0) {
+        double lo = (scale - y) + st;
+        const double hi = 1.0 + y;
+        lo = ((1.0 - hi) + y) + lo;
+        y = (hi + lo) - 1.0;
+        if (y == 0.0) y = 0.0;
+    }
+    return 0x1p-1022 * y;
+}
+
+/* ---- log1p ------------------------------------------------------------------------------ */
+#define ES_LN2_HI 6.93147180369123816490e-01
+#define ES_LN2_LO 1.90821492927058770002e-10
+#define ES_LP1 6.666666666666735130e-01
+#define ES_LP2 3.999999999940941908e-01
+#define ES_LP3 2.857142874366239149e-01
+#define ES_LP4 2.222219843214978396e-01
+#define ES_LP5 1.818357216161805012e-01
+#define ES_LP6 1.531383769920937332e-01
+#define ES_LP7 1.479819860511658591e-01
+
+/* log1p(x) for finite x > -1 (the decoder passes x = exp(-|t|) in [0,1]). */
+ES_HD double es_log1p(double x)
+{
+    const int32_t hx = es_hi32(x);
+    const int32_t ax = hx & 0x7fffffff;
+    int32_t k = 1, hu = 0;
+    double f = 0.0, c = 0.0;
+
+    if (hx < 0x3FDA827A) {                            /* x < sqrt(2)-1 */
+        if (ax >= 0x3ff00000) {                       /* x <= -1: not used by the decoder */
+            if (x == -1.0) return -es_u2d(0x7ff0000000000000ULL);
+            return (x - x) / (x - x);
+        }
+        if (ax < 0x3e200000) {                        /* |x| < 2^-29 */
+            if (ax < 0x3c900000) return x;            /* |x| < 2^-54 */
+            return x - x * x * 0.5;
+        }
+        if (hx > 0 || hx <= (int32_t)0xbfd2bec4) {    /* -0.2929 < x < 0.41422 */
+            k = 0; f = x; hu = 1;
+        }
+    } else if (hx >= 0x7ff00000) {
+        return x + x;
+    }
+    if (k != 0) {
+        double u;
+        if (hx < 0x43400000) {
+            u = 1.0 + x;
+            hu = es_hi32(u);
+            k = (hu >> 20) - 1023;
+            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+            c = c / u;
+        } else {
+            u = x;
+            hu = es_hi32(u);
+            k = (hu >> 20) - 1023;
+            c = 0.0;
+        }
+        hu &= 0x000fffff;
+        if (hu < 0x6a09e) {
+            u = es_u2d((es_d2u(u) & 0xffffffffULL) | ((uint64_t)(uint32_t)(hu | 0x3ff00000) << 32));
+        } else {
+            k += 1;
+            u = es_u2d((es_d2u(u) & 0xffffffffULL) | ((uint64_t)(uint32_t)(hu | 0x3fe00000) << 32));
+            hu = (0x00100000 - hu) >> 2;
+        }
+        f = u - 1.0;
+    }
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    if (hu == 0) {                                    /* |f| < 2^-20 */
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            c = c + dk * ES_LN2_LO;
+            return dk * ES_LN2_HI + c;
+        }
+        const double R0 = hfsq * (1.0 - 0.66666666666666666 * f);
+        if (k == 0) return f - R0;
+        return dk * ES_LN2_HI - ((R0 - (dk * ES_LN2_LO + c)) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R1 = z * ES_LP1;
+    const double z2 = z * z;
+    const double R2 = ES_LP2 + z * ES_LP3;
+    const double z4 = z2 * z2;
+    const double R3 = ES_LP4 + z * ES_LP5;
+    const double z6 = z4 * z2;
+    const double R4 = ES_LP6 + z * ES_LP7;
+    const double R = ((R1 + z2 * R2) + z4 * R3) + z6 * R4;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return dk * ES_LN2_HI - ((hfsq - (s * (hfsq + R) + (dk * ES_LN2_LO + c))) - f);
+}
+
+/* ---- numpy's logaddexp inner loop (npymath npy_logaddexp) --------------------------------- */
+#define ES_LOGE2 0.693147180559945309417232121458176568
+
+ES_HD double es_logaddexp(double x, double y, const uint64_t* tab)
+{
+    if (x == y) return x + ES_LOGE2;
+    const double d = x - y;
+    if (d > 0) return x + es_log1p(es_exp(-d, tab));
+    if (d <= 0) return y + es_log1p(es_exp(d, tab));
+    return d;                                         /* nan */
+}
+
+/* rtwm/fastpolar.py:18-23  _f_function */
+ES_HD double es_polar_f(double a, double b, const uint64_t* tab)
+{
+    return es_logaddexp(a, b, tab) - es_logaddexp(0.0, a + b, tab);
+}
+
+/* rtwm/fastpolar.py:26-29  _g_function:  b + (1 - 2u) * a  */
+ES_HD double es_polar_g(double a, double b, uint32_t u)
+{
+    return b + (1.0 - 2.0 * (double)u) * a;
+}
+
+/* rtwm/fastpolar.py:32-40  _metric_penalty (glibc-exact flavour; see DESIGN.md "penalty") */
+ES_HD double es_metric_penalty(double llr, uint32_t bit, const uint64_t* tab)
+{
+    const double al = __builtin_fabs(llr);
+    double p = es_log1p(es_exp(-al, tab));
+    const uint32_t preferred = (llr >= 0.0) ? 1u : 0u;
+    if (bit != preferred) p = p + al;
+    return p;
+}
+
+#endif /* ES_MATH_H */

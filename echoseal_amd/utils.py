@@ -1,0 +1,94 @@
+"""Host-side helpers with the reference's names (mirror of rtwm/utils.py).
+
+Band plan and keyed hop (rtwm/utils.py:19-36), dB helpers (:40-48), Butterworth design and
+resampling wrappers (:52-66), the AES-based PN stream (:83-132) and the 63-chip MLS (:135-145).
+None of this is hot-path arithmetic; it produces the tables and the key/PN schedule the HIP
+kernels consume.  The AES / HMAC code is our own (echoseal_amd.primitives) because neither
+`cryptography` nor PyCryptodome is available where this runs.
+"""
+from __future__ import annotations
+
+import hashlib
+import hmac
+import math
+from typing import Tuple
+
+import numpy as np
+from scipy.signal import butter, resample_poly
+
+from .primitives import aes128_encrypt_blocks
+
+BAND_PLAN: list[Tuple[int, int]] = [
+    (4_000, 6_000),
+    (8_000, 10_000),
+    (16_000, 18_000),
+    (18_000, 22_000),
+]
+
+
+def band_index(key: bytes, frame_ctr: int) -> int:
+    """Index into BAND_PLAN for a frame counter: HMAC-SHA256(key, ctr_be32)[0] mod 4."""
+    tag = hmac.new(key, int(frame_ctr).to_bytes(4, "big"), hashlib.sha256).digest()
+    return tag[0] % len(BAND_PLAN)
+
+
+def choose_band(key: bytes, frame_ctr: int) -> tuple[int, int]:
+    return BAND_PLAN[band_index(key, frame_ctr)]
+
+
+def db_to_lin(db: float) -> float:
+    return 10.0 ** (db / 20.0)
+
+
+def lin_to_db(lin: float) -> float:
+    return 20.0 * np.log10(lin + 1e-12)
+
+
+def butter_bandpass(lo: float, hi: float, fs: int, *, order: int = 4):
+    nyq = 0.5 * fs
+    return butter(order, [lo / nyq, hi / nyq], "band")
+
+
+def resample_to(fs_target: int, audio: np.ndarray, fs_orig: int) -> tuple[np.ndarray, int]:
+    if fs_orig == fs_target:
+        return audio, fs_orig
+    g = math.gcd(fs_orig, fs_target)
+    return resample_poly(audio, fs_target // g, fs_orig // g), fs_target
+
+
+class StreamPRNG:
+    """AES-128 block stream: block j of frame c is AES(sub_key, (c << 64 | j) big-endian)."""
+
+    def __init__(self, master_key: bytes):
+        self._sub_key = hashlib.blake2s(master_key, digest_size=16, person=b"EchoSeal").digest()
+
+    @property
+    def sub_key(self) -> bytes:
+        return self._sub_key
+
+    def blocks(self, frame_ctrs, n_blocks: int) -> np.ndarray:
+        """Keystream for many counters at once -> uint8 [len(frame_ctrs), 16 * n_blocks]."""
+        ctrs = np.asarray(frame_ctrs, dtype=np.uint64).reshape(-1)
+        inp = np.zeros((ctrs.size, n_blocks, 16), dtype=np.uint8)
+        inp[:, :, 0:8] = ctrs.astype(">u8").view(np.uint8).reshape(-1, 1, 8)
+        inp[:, :, 8:16] = np.arange(n_blocks, dtype=">u8").view(np.uint8).reshape(1, n_blocks, 8)
+        return aes128_encrypt_blocks(self._sub_key, inp).reshape(ctrs.size, 16 * n_blocks)
+
+    def bytes(self, frame_ctr: int, n: int = 64) -> bytes:
+        return self.blocks([frame_ctr], (n + 15) // 16)[0, :n].tobytes()
+
+
+def pn_bits(prng: StreamPRNG, frame_ctr: int, n_bits: int) -> np.ndarray:
+    data = prng.bytes(frame_ctr, (n_bits + 7) // 8)
+    return np.unpackbits(np.frombuffer(data, dtype="u1"))[:n_bits]
+
+
+def mseq_63() -> np.ndarray:
+    """63-chip maximal-length sequence: 6-stage LFSR, feedback bit5 ^ bit4, seed 0b111111."""
+    state = 0b111111
+    out = np.empty(63, dtype=np.uint8)
+    for i in range(63):
+        out[i] = state & 1
+        fb = ((state >> 5) ^ (state >> 4)) & 1
+        state = ((state << 1) & 0b111111) | fb
+    return out
