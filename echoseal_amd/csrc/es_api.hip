@@ -1,0 +1,217 @@
+// es_api.hip -- C ABI of libechoseal_hip.so (see include/echoseal_hip.h): context, tables,
+// argument checking and dispatch to the kernel launchers.  No torch types, no global state.
+#include "es_internal.h"
+#include "es_exp_tab.h"
+
+#include <cstring>
+#include <new>
+
+namespace {
+std::string g_create_err;
+const uint64_t kExpTab[ES_EXP_TAB_WORDS] = ES_EXP_TAB_INIT;
+
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; ok = (hipSetDevice(dev) == hipSuccess); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int fail(es_ctx* ctx, int code, const char* msg) { ctx->err = msg; return code; }
+}  // namespace
+
+extern "C" {
+
+int es_abi_version(void) { return 1; }
+
+const char* es_last_error(const es_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+es_ctx* es_create(int device, int list_size_max)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device visible"; return nullptr; }
+    if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return nullptr; }
+    if (list_size_max < 1 || list_size_max > ES_MAX_LIST) { g_create_err = "list_size_max must be in [1, 32]"; return nullptr; }
+    es_ctx* ctx = new (std::nothrow) es_ctx();
+    if (!ctx) { g_create_err = "out of host memory"; return nullptr; }
+    ctx->device = device;
+    ctx->list_size_max = list_size_max;
+    DeviceGuard g(device);
+    hipDeviceProp_t prop;
+    if (!g.ok || hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; delete ctx; return nullptr; }
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipMalloc(&ctx->d_tables, sizeof(es_band_tables)) != hipSuccess ||
+        hipMalloc(&ctx->d_data_pos, sizeof(uint16_t) * ES_POLAR_N) != hipSuccess ||
+        hipMalloc(&ctx->d_exp_tab, sizeof(kExpTab)) != hipSuccess ||
+        hipMemcpy(ctx->d_exp_tab, kExpTab, sizeof(kExpTab), hipMemcpyHostToDevice) != hipSuccess) {
+        g_create_err = "device allocation failed in es_create";
+        es_destroy(ctx);
+        return nullptr;
+    }
+    /* every launch-time buffer the SCL kernel needs is allocated here, so es_scl_batch only
+       enqueues work (hipGraph-capturable) */
+    ctx->scl_scratch_bytes = es_scl_scratch_bytes(ctx);
+    if (hipMalloc(&ctx->d_scl_scratch, ctx->scl_scratch_bytes) != hipSuccess) {
+        g_create_err = "device allocation of the SCL scratch slab failed";
+        ctx->d_scl_scratch = nullptr;
+        es_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+void es_destroy(es_ctx* ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_data_pos) (void)hipFree(ctx->d_data_pos);
+    if (ctx->d_exp_tab) (void)hipFree(ctx->d_exp_tab);
+    if (ctx->d_scl_scratch) (void)hipFree(ctx->d_scl_scratch);
+    if (ctx->d_ws_corr) (void)hipFree(ctx->d_ws_corr);
+    delete ctx;
+}
+
+int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float* taps,
+                  const int32_t* ntaps, const uint8_t* frozen)
+{
+    if (!ctx) return ES_EINVAL;
+    if (!ba || !tpl || !taps || !ntaps || !frozen) return fail(ctx, ES_EINVAL, "es_set_tables: null table pointer");
+    es_band_tables h;
+    std::memset(&h, 0, sizeof h);
+    for (int b = 0; b < ES_NBANDS; ++b) {
+        const double a0 = ba[b * 18 + 9];
+        if (a0 == 0.0) return fail(ctx, ES_EINVAL, "es_set_tables: a[0] is zero");
+        for (int k = 0; k < 18; ++k) h.ba[b][k] = ba[b * 18 + k] / a0;    // SciPy normalises by a[0]
+        for (int k = 0; k < ES_PRE_L; ++k) h.tpl[b][k] = tpl[b * ES_PRE_L + k];
+        if (ntaps[b] < 1 || ntaps[b] > ES_MAX_TAPS) return fail(ctx, ES_EINVAL, "es_set_tables: ntaps out of range");
+        h.ntaps[b] = ntaps[b];
+        for (int k = 0; k < ntaps[b]; ++k) h.taps[b][k] = taps[b * ES_MAX_TAPS + k];
+    }
+    uint16_t dpos[ES_POLAR_N];
+    std::memset(dpos, 0, sizeof dpos);
+    std::memset(&ctx->frozen, 0, sizeof ctx->frozen);
+    int n = 0;
+    for (int i = 0; i < ES_POLAR_N; ++i) {
+        if (frozen[i]) ctx->frozen.w[i >> 5] |= (1u << (i & 31));
+        else dpos[n++] = (uint16_t)i;
+    }
+    if (n != ES_POLAR_K) return fail(ctx, ES_EINVAL, "es_set_tables: frozen mask must leave exactly 448 information positions");
+    ctx->n_info = n;
+    DeviceGuard g(ctx->device);
+    ES_HIP_CHECK(ctx, hipMemcpy(ctx->d_tables, &h, sizeof h, hipMemcpyHostToDevice));
+    ES_HIP_CHECK(ctx, hipMemcpy(ctx->d_data_pos, dpos, sizeof dpos, hipMemcpyHostToDevice));
+    ctx->tables_ready = true;
+    return ES_OK;
+}
+
+#define ES_REQUIRE_READY(ctx)                                                              \
+    do {                                                                                   \
+        if (!(ctx)) return ES_EINVAL;                                                      \
+        if (!(ctx)->tables_ready) return fail((ctx), ES_ENOTREADY, "es_set_tables has not been called"); \
+    } while (0)
+
+int es_bpf_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
+                 const uint8_t* band_dev, double* y_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0 || T < 0) return fail(ctx, ES_EINVAL, "es_bpf_batch: negative size");
+    if (dtype != ES_DTYPE_F32 && dtype != ES_DTYPE_I16) return fail(ctx, ES_EINVAL, "es_bpf_batch: dtype must be f32 or i16");
+    if (B == 0 || T == 0) return ES_OK;
+    if (!frames_dev || !band_dev || !y_dev) return fail(ctx, ES_EINVAL, "es_bpf_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_bpf(ctx, frames_dev, dtype, B, T, band_dev, y_dev, (hipStream_t)stream);
+}
+
+int es_xcorr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const uint8_t* band_dev,
+                   double* corr_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0) return fail(ctx, ES_EINVAL, "es_xcorr_batch: negative size");
+    if (T < ES_PRE_L) return fail(ctx, ES_EINVAL, "es_xcorr_batch: record shorter than the 63-chip template");
+    if (B == 0) return ES_OK;
+    if (!y_dev || !band_dev || !corr_dev) return fail(ctx, ES_EINVAL, "es_xcorr_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_xcorr(ctx, y_dev, B, T, band_dev, corr_dev, (hipStream_t)stream);
+}
+
+int es_pick_batch(es_ctx* ctx, const double* corr_dev, int64_t B, int n_lags, double* thr_dev,
+                  int32_t* peaks_dev, int32_t* npeaks_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0 || n_lags < 1) return fail(ctx, ES_EINVAL, "es_pick_batch: bad size");
+    if (B == 0) return ES_OK;
+    if (!corr_dev || !thr_dev || !peaks_dev || !npeaks_dev) return fail(ctx, ES_EINVAL, "es_pick_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_pick(ctx, corr_dev, B, n_lags, thr_dev, peaks_dev, npeaks_dev, (hipStream_t)stream);
+}
+
+int es_sync_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
+                  const uint8_t* band_dev, double* y_dev, double* corr_dev, double* thr_dev,
+                  int32_t* peaks_dev, int32_t* npeaks_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (T < ES_PRE_L) return fail(ctx, ES_EINVAL, "es_sync_batch: record shorter than the 63-chip template");
+    if (B <= 0) return B == 0 ? ES_OK : fail(ctx, ES_EINVAL, "es_sync_batch: negative batch");
+    DeviceGuard g(ctx->device);
+    const int n_lags = T - (ES_PRE_L - 1);
+    double* corr = corr_dev;
+    if (!corr) {                                          // workspace grows monotonically; never freed in-call
+        const size_t need = (size_t)B * n_lags * sizeof(double);
+        if (need > ctx->ws_corr_bytes) {
+            if (ctx->d_ws_corr) ES_HIP_CHECK(ctx, hipFree(ctx->d_ws_corr));
+            ctx->d_ws_corr = nullptr; ctx->ws_corr_bytes = 0;
+            ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_ws_corr, need));
+            ctx->ws_corr_bytes = need;
+        }
+        corr = ctx->d_ws_corr;
+    }
+    int rc = es_bpf_batch(ctx, frames_dev, dtype, B, T, band_dev, y_dev, stream);
+    if (rc) return rc;
+    rc = es_xcorr_batch(ctx, y_dev, B, T, band_dev, corr, stream);
+    if (rc) return rc;
+    return es_pick_batch(ctx, corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, stream);
+}
+
+int es_llr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const int32_t* start_dev,
+                 const uint8_t* band_dev, const uint8_t* pn_dev, int variant, float* llr_dev,
+                 int32_t* best_s_dev, float* score_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0 || T < 0) return fail(ctx, ES_EINVAL, "es_llr_batch: negative size");
+    if (variant != 0 && variant != 1) return fail(ctx, ES_EINVAL, "es_llr_batch: variant must be 0 or 1");
+    if (B == 0) return ES_OK;
+    if (!y_dev || !band_dev || !pn_dev || !llr_dev) return fail(ctx, ES_EINVAL, "es_llr_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_llr(ctx, y_dev, B, T, start_dev, band_dev, pn_dev, variant, llr_dev, best_s_dev,
+                         score_dev, (hipStream_t)stream);
+}
+
+int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int list_size,
+                 int skip_if_hard_ok, uint8_t* hard_info_dev, uint8_t* hard_ok_dev,
+                 uint8_t* cand_info_dev, double* cand_metric_dev, uint8_t* cand_ok_dev,
+                 int32_t* ncand_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0) return fail(ctx, ES_EINVAL, "es_scl_batch: negative batch");
+    if (dtype != ES_DTYPE_F32 && dtype != ES_DTYPE_F64) return fail(ctx, ES_EINVAL, "es_scl_batch: dtype must be f32 or f64");
+    if (list_size < 1 || list_size > ctx->list_size_max || (list_size & (list_size - 1)))
+        return fail(ctx, ES_EINVAL, "es_scl_batch: list_size must be a power of two in [1, list_size_max]");
+    if (B == 0) return ES_OK;
+    if (!llr_dev || !hard_info_dev || !hard_ok_dev || !cand_info_dev || !cand_metric_dev || !cand_ok_dev || !ncand_dev)
+        return fail(ctx, ES_EINVAL, "es_scl_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_scl(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
+                         cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
+}
+
+int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8_t* code_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0) return fail(ctx, ES_EINVAL, "es_polar_encode_batch: negative batch");
+    if (B == 0) return ES_OK;
+    if (!info_dev || !code_dev) return fail(ctx, ES_EINVAL, "es_polar_encode_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_polar_encode(ctx, info_dev, B, code_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"

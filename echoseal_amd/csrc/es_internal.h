@@ -1,0 +1,64 @@
+/* es_internal.h -- private declarations shared by the HIP translation units. */
+#ifndef ES_INTERNAL_H
+#define ES_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/echoseal_hip.h"
+
+struct es_frozen_mask { uint32_t w[32]; };            /* bit i set = index i frozen */
+
+struct es_band_tables {
+    double ba[ES_NBANDS][18];                         /* b[0..8], a[0..8] (already divided by a0) */
+    double tpl[ES_NBANDS][64];                        /* 63 taps + pad */
+    float  taps[ES_NBANDS][ES_MAX_TAPS];
+    int32_t ntaps[ES_NBANDS];
+};
+
+struct es_ctx {
+    int device = 0;
+    int list_size_max = 8;
+    int num_cu = 256;
+    bool tables_ready = false;
+    std::string err;
+
+    es_frozen_mask frozen{};
+    int n_info = 0;
+
+    /* device-resident tables */
+    es_band_tables* d_tables = nullptr;
+    uint16_t* d_data_pos = nullptr;                   /* [448] ascending information indices */
+    uint64_t* d_exp_tab = nullptr;                    /* [256] */
+    /* scratch */
+    double* d_scl_scratch = nullptr;  size_t scl_scratch_bytes = 0;
+    double* d_ws_corr = nullptr;      size_t ws_corr_bytes = 0;
+};
+
+#define ES_HIP_CHECK(ctx, expr)                                                         \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);             \
+            return ES_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+/* launchers implemented in the kernel translation units */
+size_t es_scl_scratch_bytes(const es_ctx* ctx);
+int es_launch_scl(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
+                  uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
+                  uint8_t* cand_ok, int32_t* ncand, hipStream_t st);
+int es_launch_polar_encode(es_ctx* ctx, const uint8_t* info, int64_t B, uint8_t* code, hipStream_t st);
+int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, const uint8_t* band,
+                  double* y, hipStream_t st);
+int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
+                    hipStream_t st);
+int es_launch_pick(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
+                   int32_t* npeaks, hipStream_t st);
+int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t* start,
+                  const uint8_t* band, const uint8_t* pn, int variant, float* llr, int32_t* best_s,
+                  float* score, hipStream_t st);
+
+#endif

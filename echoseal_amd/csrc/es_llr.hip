@@ -1,0 +1,283 @@
+// es_llr.hip -- per-frame soft demodulation (WatermarkDetector._llr, rtwm/detector.py:296-416)
+// for gfx950: matched filter -> integer chip-shift search -> PN despread -> robust scaling.
+//
+// One 256-thread block (4 waves) per frame.  LDS holds the frame slice, the taps, the +-1 PN
+// symbols, the matched-filter window and the despread vector (~23 KB, 6 blocks per CU).
+//
+// Numerics follow the reference's NumPy float32 data flow step by step:
+//   * matched filter: float64 accumulation of exact float32 products, ascending sample order,
+//     rounded once to float32 (the reference's BLAS sdot order is machine dependent; see
+//     oracle/c/eso_dsp.c for the rationale -- kernel and oracle use the same definition);
+//   * every float32 sum (shift scores, mean, variance) reproduces NumPy's pairwise reduction:
+//     blocks of <=128 elements, 8 strided accumulators combined as ((0+1)+(2+3))+((4+5)+(6+7)),
+//     recursive halving above 128.  With <=1024 elements that tree has at most 8 leaves, which is
+//     exactly one wave: lane = leaf*8 + accumulator, combined with xor-shuffles 1,2,4 (inside a
+//     leaf) and 8,16,32 (across leaves).  Absent leaves contribute +0.0, which is exact;
+//   * medians are exact order statistics (wave-level radix select on the 32-bit keys).
+//
+// Build with -ffp-contract=off.
+#include "es_internal.h"
+
+namespace {
+
+constexpr int NPAY = ES_POLAR_N;
+constexpr int PAYLOAD_START = ES_PRE_L + ES_HDR_L;   // 191
+constexpr int LLR_THREADS = 256;
+constexpr int MAX_RX = NPAY + ES_MAX_TAPS;           // prefix + payload
+constexpr int MAX_WIN = NPAY + 2 * ES_MAX_TAPS + 8;  // matched-filter window
+
+struct PwPlan { int start[16]; int len[16]; };
+
+// NumPy pairwise_sum split points for a vector of n (<= 1024) elements, laid out on a full
+// depth-4 binary tree (slots 0..15).  A node longer than 128 is split at h = n/2 - (n/2)%8 into
+// (slot, h) and (slot + span/2, n - h); a node that is already <= 128 long stays where it is and
+// its unused sibling slots keep length 0.  Four levels suffice: a depth-4 piece is at most
+// n/16 + 14 <= 78 elements.
+__device__ __forceinline__ void pw_plan_build(PwPlan& p, int n)
+{
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) { p.start[s] = 0; p.len[s] = 0; }
+    p.len[0] = n;
+    #pragma unroll
+    for (int span = 16; span >= 2; span >>= 1) {
+        #pragma unroll
+        for (int s = 0; s < 16; s += span) {
+            if (p.len[s] > 128) {
+                int h = p.len[s] / 2; h -= h % 8;
+                p.start[s + span / 2] = p.start[s] + h;
+                p.len[s + span / 2] = p.len[s] - h;
+                p.len[s] = h;
+            }
+        }
+    }
+}
+
+// One wave evaluates NumPy's pairwise float32 sum of get(i), i in [0, n), using the plan:
+// lane = leaf*4 + jj owns accumulators jj and jj+4 of its leaf.  All lanes return the total.
+template <typename F>
+__device__ __forceinline__ float wave_pairwise_sum(const PwPlan& p, int lane, F get)
+{
+    const int leaf = lane >> 2, jj = lane & 3;
+    int st = 0, ln = 0;
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) if (s == leaf) { st = p.start[s]; ln = p.len[s]; }
+    float r;
+    if (ln >= 8) {
+        float ra = get(st + jj), rb = get(st + jj + 4);
+        const int full = ln - (ln % 8);
+        for (int i = 8; i < full; i += 8) { ra = ra + get(st + i + jj); rb = rb + get(st + i + jj + 4); }
+        ra = ra + __shfl_xor(ra, 1); rb = rb + __shfl_xor(rb, 1);      // (r0+r1) , (r4+r5)
+        ra = ra + __shfl_xor(ra, 2); rb = rb + __shfl_xor(rb, 2);      // +(r2+r3), +(r6+r7)
+        r = ra + rb;
+        for (int i = full; i < ln; ++i) r = r + get(st + i);
+    } else {
+        r = 0.0f;
+        for (int i = 0; i < ln; ++i) r = r + get(st + i);
+    }
+    r = r + __shfl_xor(r, 4);
+    r = r + __shfl_xor(r, 8);
+    r = r + __shfl_xor(r, 16);
+    r = r + __shfl_xor(r, 32);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t f32_key(float x)
+{
+    uint32_t b; __builtin_memcpy(&b, &x, 4);
+    return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k)
+{
+    const uint32_t b = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+    float x; __builtin_memcpy(&x, &b, 4); return x;
+}
+
+// k-th smallest of v[0..n) by one wave: bitwise radix select with ballot popcounts.
+__device__ float wave_select_f32(const float* v, int n, int k, int lane)
+{
+    uint32_t prefix = 0;
+    int kk = k;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t himask = (bit == 31) ? 0u : (~0u << (bit + 1));
+        int zeros = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            bool z = false;
+            if (i < n) {
+                const uint32_t key = f32_key(v[i]);
+                z = ((key & himask) == prefix) && !((key >> bit) & 1u);
+            }
+            zeros += __popcll(__ballot(z));
+        }
+        if (kk >= zeros) { kk -= zeros; prefix |= (1u << bit); }
+    }
+    return key_f32(prefix);
+}
+
+__device__ float wave_median_f32(const float* v, int n, int lane)
+{
+    if (n & 1) return wave_select_f32(v, n, n / 2, lane);
+    const float lo = wave_select_f32(v, n, n / 2 - 1, lane);
+    const float hi = wave_select_f32(v, n, n / 2, lane);
+    return (lo + hi) / 2.0f;
+}
+
+__global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __restrict__ y, long long B,
+        int T, const int32_t* __restrict__ start, const uint8_t* __restrict__ band,
+        const uint8_t* __restrict__ pn_rows, int variant, const es_band_tables* __restrict__ tabs,
+        float* __restrict__ llr, int32_t* __restrict__ best_s_out, float* __restrict__ score_out)
+{
+    __shared__ float s_rx[MAX_RX];
+    __shared__ float s_h[ES_MAX_TAPS];
+    __shared__ float s_pn[NPAY];
+    __shared__ float s_win[MAX_WIN];
+    __shared__ float s_d[NPAY];
+    __shared__ float s_dev[NPAY];
+    __shared__ float s_score[4][2];
+    __shared__ int   s_shift[4];
+    __shared__ float s_stats[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    for (long long rec = blockIdx.x; rec < B; rec += gridDim.x) {
+        float* out = llr + rec * NPAY;
+        const int st0 = start ? start[rec] : 0;
+        int flen = T - st0; if (flen > ES_FRAME_LEN) flen = ES_FRAME_LEN;
+        const int bi = band[rec];
+        const int ntaps = tabs->ntaps[bi];
+        const int mem = ntaps - 1;
+        const int npl = flen - PAYLOAD_START;                         // payload samples present
+        if (st0 < 0 || npl <= 0) {                                    // detector.py:320-325
+            for (int i = tid; i < NPAY; i += LLR_THREADS) out[i] = 0.0f;
+            if (tid == 0) { if (best_s_out) best_s_out[rec] = 0; if (score_out) { score_out[2 * rec] = -1.0f; score_out[2 * rec + 1] = -1.0f; } }
+            continue;
+        }
+        const double* fr = y + rec * T + st0;
+        const int prefix = mem < PAYLOAD_START ? mem : PAYLOAD_START; // :327
+        const int nfull = prefix + npl;
+        for (int i = tid; i < nfull; i += LLR_THREADS) s_rx[i] = (float)fr[PAYLOAD_START - prefix + i];
+        for (int i = tid; i < ntaps; i += LLR_THREADS) s_h[i] = tabs->taps[bi][i];
+        const int n = NPAY < npl ? NPAY : npl;                        // :337
+        const uint8_t* pnr = pn_rows + rec * ES_PN_BYTES;
+        const int pn_off = (variant == 0) ? PAYLOAD_START : 0;        // :306-312
+        for (int i = tid; i < n; i += LLR_THREADS) {
+            const int bpos = pn_off + i;
+            const uint32_t bit = (pnr[bpos >> 3] >> (7 - (bpos & 7))) & 1u;
+            s_pn[i] = 2.0f * (float)bit - 1.0f;
+        }
+        __syncthreads();
+
+        // ---- geometry (:335-363)
+        const int nmf = nfull + ntaps - 1;
+        const int offset = prefix + mem;
+        int raw_shift = n / 2;
+        if (4 * ntaps < raw_shift) raw_shift = 4 * ntaps;
+        if (ES_HDR_L < raw_shift) raw_shift = ES_HDR_L;
+        const int max_shift = mem > raw_shift ? mem : raw_shift;
+        const int wstart = offset - max_shift > 0 ? offset - max_shift : 0;
+        const int wstop = nmf < offset + n + max_shift ? nmf : offset + n + max_shift;
+        const int nwin = wstop - wstart;
+        const int base = offset - wstart;
+        int guard = ntaps / 2 > 24 ? ntaps / 2 : 24;
+        if (n / 4 < guard) guard = n / 4;
+        if (guard >= n) guard = n / 4 > 0 ? n / 4 : 0;
+
+        // ---- matched filter window (:334): mf[j] = sum_i rx[i] h[j-i]
+        for (int w = tid; w < nwin; w += LLR_THREADS) {
+            const int jj = wstart + w;
+            int i0 = jj - (ntaps - 1); if (i0 < 0) i0 = 0;
+            const int i1 = jj < nfull - 1 ? jj : nfull - 1;
+            double acc = 0.0;
+            for (int i = i0; i <= i1; ++i) acc += (double)s_rx[i] * (double)s_h[jj - i];
+            s_win[w] = (float)acc;
+        }
+        __syncthreads();
+
+        // ---- shift search (:366-379): score(s) = mean(|win[base+s+i] * pn[i]|, i >= guard)
+        PwPlan plan;
+        pw_plan_build(plan, n - guard);
+        const float cnt_f = (float)(n - guard);
+        float my_best = -1.0f, my_second = -1.0f; int my_s = 0;
+        for (int s = -max_shift + wv; s <= max_shift; s += 4) {      // ascending within a wave
+            const int i0 = base + s;
+            if (i0 < 0 || i0 + n > nwin) continue;
+            const float* a = s_win + i0 + guard;
+            const float* b = s_pn + guard;
+            const float sum = wave_pairwise_sum(plan, lane, [&](int i) { return __builtin_fabsf(a[i] * b[i]); });
+            const float score = sum / cnt_f;
+            if (score > my_best) { my_second = my_best; my_best = score; my_s = s; }
+            else if (score > my_second) my_second = score;
+        }
+        if (lane == 0) { s_score[wv][0] = my_best; s_score[wv][1] = my_second; s_shift[wv] = my_s; }
+        __syncthreads();
+        // first maximum in ascending-shift order wins (strict > in the reference)
+        float best = -1.0f, second = -1.0f; int best_s = 0;
+        #pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float b0 = s_score[w][0], b1 = s_score[w][1]; const int sh = s_shift[w];
+            if (b0 > best || (b0 == best && sh < best_s)) {
+                if (best > second) second = best;
+                best = b0; best_s = sh;
+            } else if (b0 > second) second = b0;
+            if (b1 > second) second = b1;
+        }
+
+        // ---- despread at the chosen shift (:382-385)
+        const int a0 = base + best_s;
+        for (int i = tid; i < n; i += LLR_THREADS) s_d[i] = s_win[a0 + i] * s_pn[i];
+        __syncthreads();
+
+        // ---- robust statistics on the tail (:395-404), wave 0
+        const int toff = (n > guard + 8) ? guard : 0;
+        const int nt = n - toff;
+        if (wv == 0) {
+            const float* tail = s_d + toff;
+            PwPlan tp; pw_plan_build(tp, nt);
+            const float mu = wave_pairwise_sum(tp, lane, [&](int i) { return tail[i]; }) / (float)nt;
+            const float medv = wave_median_f32(tail, nt, lane);
+            for (int i = lane; i < nt; i += 64) s_dev[i] = __builtin_fabsf(tail[i] - medv);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            const double mad = (double)wave_median_f32(s_dev, nt, lane) + 1e-12;
+            const float var = wave_pairwise_sum(tp, lane, [&](int i) { const float c = tail[i] - mu; return c * c; }) / (float)nt;
+            const double sigma_mad = 1.4826 * mad;
+            const double sigma_std = (double)__builtin_sqrtf(var) + 1e-12;
+            double sigma = sigma_mad > sigma_std ? sigma_mad : sigma_std;
+            if (0.1 > sigma) sigma = 0.1;
+            double scale = 2.0 / (sigma * sigma);
+            if (scale < 0.5) scale = 0.5;
+            if (scale > 30.0) scale = 30.0;
+            if (lane == 0) { s_stats[0] = mu; s_stats[1] = (float)scale; }
+        }
+        __syncthreads();
+        const float mu = s_stats[0], scale32 = s_stats[1];
+        for (int i = tid; i < NPAY; i += LLR_THREADS) {
+            float v = 0.0f;
+            if (i < n) {
+                v = (s_d[i] - mu) * scale32;                          // :397,405
+                if (v < -12.0f) v = -12.0f;
+                if (v > 12.0f) v = 12.0f;
+            }
+            out[i] = v;
+        }
+        if (tid == 0) {
+            if (best_s_out) best_s_out[rec] = best_s;
+            if (score_out) { score_out[2 * rec] = best; score_out[2 * rec + 1] = second; }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t* start,
+                  const uint8_t* band, const uint8_t* pn, int variant, float* llr, int32_t* best_s,
+                  float* score, hipStream_t st)
+{
+    long long blocks = B;
+    const long long cap = (long long)ctx->num_cu * 12;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(es_llr_kernel, dim3((unsigned)blocks), dim3(LLR_THREADS), 0, st, y, (long long)B, T,
+                       start, band, pn, variant, ctx->d_tables, llr, best_s, score);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}

@@ -1,0 +1,437 @@
+// es_scl.hip -- Polar(1024,448)+CRC-8 hard-decision shortcut and successive-cancellation LIST
+// decoder for gfx950, one 64-lane wavefront per frame.
+//
+// What it computes is PolarCode.decode of the reference (rtwm/fastpolar.py:254-359) up to, but
+// not including, the validator callback: the hard-decision candidate with its CRC flag
+// (:260-268) and the L list survivors in ascending path-metric order with metrics and CRC flags
+// (:278-341).  The host applies validator / selection rules (:268-276, :335-359) to that list.
+//
+// Mapping to the hardware (no dense contraction here, so no MFMA; the work is float64 VALU and
+// cross-lane bookkeeping):
+//   * 64 lanes = L paths x P lanes (P = 64/L).  All paths of a frame advance in lock step, so the
+//     whole decoder is wave-synchronous: no __syncthreads in the bit loop, only wave fences.
+//   * LLR tree: depth d holds 1024>>d values per path.  Depths 1..3 (512+256+128 values, touched
+//     2/4/8 times per decode) live in an HBM/L2 scratch slab owned by the wave; depths 4..10
+//     (127 values) live in LDS.  Depth 0 (channel LLRs) is read straight from the input.
+//   * No path copies.  Every path owns one storage slot per depth; a path remembers, per depth,
+//     WHICH slot holds its data (6 bits per depth packed in a 64-bit register, one word for the
+//     LLR tree and one for the partial-sum tree).  A list sort only permutes those two words and
+//     the metric with ds_bpermute (__shfl).  A depth that is recomputed is always written to the
+//     path's own slot; all paths recompute the same depths at the same time, so a slot is never
+//     overwritten while another path still needs it.
+//   * Decided bits are not stored per path; each information step records (parent, bit) per
+//     survivor and the 448 data bits are recovered by a trace-back at the end.
+//   * Path-metric sort: candidates 2p+b sit in lanes (p, q=b); rank = number of candidates that
+//     sort strictly before (metric, then candidate index) -- exactly Python's stable list.sort.
+//   * float64 f / penalty use es_math.h (glibc-exact exp/log1p) with the 2 KB exp table in LDS.
+//
+// Build with -ffp-contract=off: every rounding step in es_math.h is explicit.
+#include "es_internal.h"
+#include "es_math.h"
+
+namespace {
+
+constexpr int N = ES_POLAR_N;
+constexpr int NLEV = 10;
+constexpr int KINFO = ES_POLAR_K;         // 448 data positions (440 info + 8 CRC)
+constexpr int GDEPTH = 3;                 // depths 1..GDEPTH live in global scratch
+constexpr int GSLOT = 512 + 256 + 128;    // doubles per path slot in global scratch
+constexpr int LDS_ROW = 136;              // 128 doubles + 8 pad (bank spread between slots)
+
+__device__ __forceinline__ void wave_fence_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wave_fence_global()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int L>
+struct SclWave {
+    double   alphaS[L][LDS_ROW];          // depth d (4..10): values at [1024>>d, 2*(1024>>d))
+    double   candm[2 * L];
+    uint32_t betaL[L][32];                // left-sibling partial sums, block of S bits at bit S
+    uint32_t curb[L][16];                 // transient right block while folding upward
+    uint32_t hardw[32];
+    uint8_t  tb[KINFO][L];                // trace-back: (parent << 1) | bit
+    uint8_t  sel[L < 4 ? 4 : L];
+    uint8_t  outb[L][56];
+};
+
+template <int L> struct SclCfg { static constexpr int WPB = (L <= 8) ? 4 : (L == 16 ? 2 : 1); };
+
+struct SclArgs {
+    const void* llr; int is_f64; long long B;
+    es_frozen_mask frozen;
+    const uint16_t* data_pos;
+    const uint64_t* exp_tab;
+    double* scratch;
+    uint8_t* hard_info; uint8_t* hard_ok;
+    uint8_t* cand_info; double* cand_metric; uint8_t* cand_ok; int32_t* ncand;
+    int skip_if_hard_ok;
+};
+
+__device__ __forceinline__ uint64_t ptr_set(uint64_t p, int depth, int slot)
+{
+    const int sh = 6 * (depth - 1);
+    return (p & ~(63ULL << sh)) | ((uint64_t)slot << sh);
+}
+__device__ __forceinline__ int ptr_get(uint64_t p, int depth) { return (int)((p >> (6 * (depth - 1))) & 63ULL); }
+
+__device__ __forceinline__ uint8_t crc8_bytes(const uint8_t* b, int n)
+{
+    uint32_t reg = 0;
+    for (int i = 0; i < n; ++i) {
+        reg ^= b[i];
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
+    }
+    return (uint8_t)reg;
+}
+
+template <int L>
+__global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
+{
+    constexpr int WPB = SclCfg<L>::WPB;
+    constexpr int P = 64 / L;
+    __shared__ __attribute__((aligned(16))) uint64_t s_exp[ES_EXP_TAB_WORDS];
+    __shared__ uint16_t s_dpos[KINFO];
+    __shared__ SclWave<L> s_wave[WPB];
+
+    for (int i = threadIdx.x; i < ES_EXP_TAB_WORDS; i += blockDim.x) s_exp[i] = a.exp_tab[i];
+    for (int i = threadIdx.x; i < KINFO; i += blockDim.x) s_dpos[i] = a.data_pos[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int path = lane / P;
+    const int q = lane % P;
+    SclWave<L>& W = s_wave[wv];
+    const long long wave_id = (long long)blockIdx.x * WPB + wv;
+    const long long n_waves = (long long)gridDim.x * WPB;
+    double* const scr = a.scratch + wave_id * (long long)(L * GSLOT);
+    const uint64_t* const tab = s_exp;
+
+    for (long long f = wave_id; f < a.B; f += n_waves) {
+        const float* llr32 = (const float*)a.llr + f * N;
+        const double* llr64 = (const double*)a.llr + f * N;
+
+        // ---------------- hard decision -> butterfly -> data bits -> CRC (fastpolar.py:260-268)
+        {
+            uint32_t word = 0;
+            for (int c = 0; c < 16; ++c) {
+                const double v = a.is_f64 ? llr64[64 * c + lane] : (double)llr32[64 * c + lane];
+                const unsigned long long m = __ballot(v > 0.0);
+                if (((lane & 31) >> 1) == c) word = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+            }
+            word ^= (word >> 1) & 0x55555555u;
+            word ^= (word >> 2) & 0x33333333u;
+            word ^= (word >> 4) & 0x0f0f0f0fu;
+            word ^= (word >> 8) & 0x00ff00ffu;
+            word ^= (word >> 16) & 0x0000ffffu;
+            #pragma unroll
+            for (int hw = 1; hw < 32; hw <<= 1) {
+                const uint32_t o = __shfl_xor(word, hw);
+                if (!((lane & 31) & hw)) word ^= o;
+            }
+            if (lane < 32) W.hardw[lane] = word;
+            wave_fence_lds();
+            if (lane < 56) {
+                uint32_t byte = 0;
+                #pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int pos = s_dpos[8 * lane + b];
+                    byte |= ((W.hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
+                }
+                W.outb[0][lane] = (uint8_t)byte;
+            }
+            wave_fence_lds();
+            int ok = 0;
+            if (lane == 0) ok = (crc8_bytes(W.outb[0], ES_INFO_BYTES) == W.outb[0][ES_INFO_BYTES]);
+            ok = __shfl(ok, 0);
+            if (lane < ES_INFO_BYTES) a.hard_info[f * ES_INFO_BYTES + lane] = W.outb[0][lane];
+            if (lane == 0) a.hard_ok[f] = (uint8_t)ok;
+            wave_fence_lds();
+            if (ok && a.skip_if_hard_ok) {
+                if (lane == 0) a.ncand[f] = 0;
+                continue;
+            }
+        }
+
+        // ---------------- list decoding (fastpolar.py:278-330)
+        uint64_t ptrA = 0, ptrB = 0;      // every path starts as a mirror of path 0
+        double metric = 0.0;
+        int cnt = 1;                      // live paths
+        int info_idx = 0;
+        if (lane < 32) { for (int s = 0; s < L; ++s) W.betaL[s][lane] = 0; }
+        wave_fence_lds();
+
+        for (int i = 0; i < N; ++i) {
+            // --- LLR chain: recompute the depths that changed since leaf i-1 (fastpolar.py:127-154)
+            const int top = (i == 0) ? 1 : NLEV - __builtin_ctz((unsigned)i);
+            for (int d = top; d <= NLEV; ++d) {
+                const int S = N >> d;
+                const bool is_g = (i >> (NLEV - d)) & 1;
+                const int ps = (d > 1) ? ptr_get(ptrA, d - 1) : 0;
+                const int bs = ptr_get(ptrB, d);
+                for (int j = q; j < S; j += P) {
+                    double pa, pb;
+                    if (d == 1) {
+                        if (a.is_f64) { pa = llr64[j]; pb = llr64[j + S]; }
+                        else { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }
+                    } else if (d - 1 <= GDEPTH) {
+                        const double* par = scr + ps * GSLOT + (N - 4 * S);   // depth d-1 offset: 0,512,768
+                        pa = par[j]; pb = par[j + S];
+                    } else {
+                        const double* par = &W.alphaS[ps][2 * S];
+                        pa = par[j]; pb = par[j + S];
+                    }
+                    double out;
+                    if (is_g) {
+                        const uint32_t wbits = W.betaL[bs][(S + j) >> 5];
+                        out = es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u);
+                    } else {
+                        out = es_polar_f(pa, pb, tab);
+                    }
+                    if (d <= GDEPTH) scr[path * GSLOT + (N - 2 * S) + j] = out;  // depth d offset
+                    else W.alphaS[path][S + j] = out;
+                }
+                if (d <= GDEPTH) wave_fence_global(); else wave_fence_lds();
+                ptrA = ptr_set(ptrA, d, path);
+            }
+            const double lam = W.alphaS[path][1];
+
+            // --- decision
+            const bool frozen = (a.frozen.w[i >> 5] >> (i & 31)) & 1u;
+            const double al = __builtin_fabs(lam);
+            const double lp = es_log1p(es_exp(-al, tab));
+            const uint32_t pref = (lam >= 0.0) ? 1u : 0u;
+            uint32_t bit = 0;
+            if (frozen) {                                             // fastpolar.py:281-286
+                double pen = lp;
+                if (pref != 0u) pen = lp + al;
+                metric = metric + pen;
+            } else {                                                  // fastpolar.py:288-330
+                double pen = lp;
+                if ((uint32_t)q != pref) pen = lp + al;
+                const double m = metric + pen;
+                const bool is_cand = (q < 2) && (path < cnt);
+                const int c = 2 * path + q;
+                if (is_cand) W.candm[c] = m;
+                wave_fence_lds();
+                const int nc = 2 * cnt;
+                int rank = 0;
+                for (int k = 0; k < nc; ++k) {
+                    const double mk = W.candm[k];
+                    rank += ((mk < m) || (mk == m && k < c)) ? 1 : 0;
+                }
+                const int keep = nc < L ? nc : L;
+                if (is_cand && rank < keep) W.sel[rank] = (uint8_t)c;
+                wave_fence_lds();
+                const int myc = W.sel[path < keep ? path : 0];
+                const int parent = myc >> 1;
+                bit = (uint32_t)(myc & 1);
+                const double nm = W.candm[myc];
+                ptrA = __shfl(ptrA, parent * P);
+                ptrB = __shfl(ptrB, parent * P);
+                metric = nm;
+                if (q == 0 && path < keep) W.tb[info_idx][path] = (uint8_t)myc;
+                cnt = keep;
+                ++info_idx;
+                wave_fence_lds();
+            }
+
+            // --- partial sums: fold upward while the node is a right child (fastpolar.py:156-183)
+            const int t = __builtin_ctz(~(unsigned)i);                // trailing ones of i
+            if (t < NLEV) {
+                uint32_t cur = bit;
+                const int t5 = t < 5 ? t : 5;
+                for (int s = 0; s < t5; ++s) {
+                    const int S = 1 << s;
+                    const int bs = ptr_get(ptrB, NLEV - s);
+                    const uint32_t left = (W.betaL[bs][0] >> S) & ((1u << S) - 1u);
+                    cur = (left ^ cur) | (cur << S);
+                }
+                if (t <= 5) {
+                    if (q == 0) {
+                        if (t < 5) {
+                            const int Sp = 1 << t;
+                            const uint32_t mask = ((1u << Sp) - 1u) << Sp;
+                            const uint32_t w = W.betaL[path][0];
+                            W.betaL[path][0] = (w & ~mask) | (cur << Sp);
+                        } else {
+                            W.betaL[path][1] = cur;
+                        }
+                    }
+                } else {
+                    if (q == 0) W.curb[path][0] = cur;
+                    wave_fence_lds();
+                    for (int s = 5; s < t; ++s) {
+                        const int Wd = 1 << (s - 5);                  // words in the current block
+                        const int bs = ptr_get(ptrB, NLEV - s);
+                        for (int w = q; w < Wd; w += P) {
+                            const uint32_t c0 = W.curb[path][w];
+                            const uint32_t lf = W.betaL[bs][Wd + w];
+                            W.curb[path][Wd + w] = c0;
+                            W.curb[path][w] = c0 ^ lf;
+                        }
+                        wave_fence_lds();
+                    }
+                    const int Wp = 1 << (t - 5);
+                    for (int w = q; w < Wp; w += P) W.betaL[path][Wp + w] = W.curb[path][w];
+                }
+                ptrB = ptr_set(ptrB, NLEV - t, path);
+                wave_fence_lds();
+            }
+        }
+
+        // ---------------- final ordering (fastpolar.py:335), trace-back, CRC
+        if (q == 0) W.candm[path] = metric;
+        wave_fence_lds();
+        int rank = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const double mk = W.candm[k];
+            rank += ((mk < metric) || (mk == metric && k < path)) ? 1 : 0;
+        }
+        if (q == 0 && path < cnt) {
+            int cur = path;
+            uint32_t acc = 0;
+            for (int tt = KINFO - 1; tt >= 0; --tt) {
+                const uint32_t c = W.tb[tt][cur];
+                acc |= (c & 1u) << (7 - (tt & 7));
+                cur = (int)(c >> 1);
+                if ((tt & 7) == 0) { W.outb[path][tt >> 3] = (uint8_t)acc; acc = 0; }
+            }
+            const int ok = crc8_bytes(W.outb[path], ES_INFO_BYTES) == W.outb[path][ES_INFO_BYTES];
+            a.cand_metric[f * L + rank] = metric;
+            a.cand_ok[f * L + rank] = (uint8_t)ok;
+        }
+        wave_fence_lds();
+        if (path < cnt) {
+            for (int k = q; k < ES_INFO_BYTES; k += P)
+                a.cand_info[(f * L + rank) * ES_INFO_BYTES + k] = W.outb[path][k];
+        }
+        if (lane == 0) a.ncand[f] = cnt;
+        wave_fence_lds();
+    }
+}
+
+// ---- polar encode (fastpolar.py:237-252): one wave per frame --------------------------------
+__global__ __launch_bounds__(256) void es_polar_encode_kernel(const uint8_t* info, long long B,
+                                                              const uint16_t* data_pos, uint8_t* code)
+{
+    __shared__ uint16_t s_dpos[KINFO];
+    __shared__ uint32_t s_words[4][32];
+    __shared__ uint8_t s_bytes[4][56];
+    for (int i = threadIdx.x; i < KINFO; i += blockDim.x) s_dpos[i] = data_pos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long n_waves = (long long)gridDim.x * 4;
+    for (long long f = (long long)blockIdx.x * 4 + wv; f < B; f += n_waves) {
+        if (lane < ES_INFO_BYTES) s_bytes[wv][lane] = info[f * ES_INFO_BYTES + lane];
+        if (lane < 32) s_words[wv][lane] = 0;
+        wave_fence_lds();
+        if (lane == 0) s_bytes[wv][ES_INFO_BYTES] = crc8_bytes(s_bytes[wv], ES_INFO_BYTES);
+        wave_fence_lds();
+        for (int tpos = lane; tpos < KINFO; tpos += 64) {
+            const uint32_t bit = (s_bytes[wv][tpos >> 3] >> (7 - (tpos & 7))) & 1u;
+            const int pos = s_dpos[tpos];
+            if (bit) atomicOr(&s_words[wv][pos >> 5], 1u << (pos & 31));
+        }
+        wave_fence_lds();
+        uint32_t word = s_words[wv][lane & 31];
+        word ^= (word >> 1) & 0x55555555u;
+        word ^= (word >> 2) & 0x33333333u;
+        word ^= (word >> 4) & 0x0f0f0f0fu;
+        word ^= (word >> 8) & 0x00ff00ffu;
+        word ^= (word >> 16) & 0x0000ffffu;
+        #pragma unroll
+        for (int hw = 1; hw < 32; hw <<= 1) {
+            const uint32_t o = __shfl_xor(word, hw);
+            if (!((lane & 31) & hw)) word ^= o;
+        }
+        if (lane < 32) s_words[wv][lane] = word;
+        wave_fence_lds();
+        for (int k = lane; k < N; k += 64) code[f * N + k] = (uint8_t)((s_words[wv][k >> 5] >> (k & 31)) & 1u);
+        wave_fence_lds();
+    }
+}
+
+template <int L>
+long long scl_blocks(const es_ctx* ctx, long long B)
+{
+    constexpr int WPB = SclCfg<L>::WPB;
+    long long blocks = (B + WPB - 1) / WPB;
+    const long long max_blocks = (long long)ctx->num_cu * 2;    // LDS admits two blocks per CU
+    return blocks < max_blocks ? blocks : max_blocks;
+}
+
+template <int L>
+size_t scl_scratch_need(const es_ctx* ctx)
+{
+    return (size_t)ctx->num_cu * 2 * SclCfg<L>::WPB * L * GSLOT * sizeof(double);
+}
+
+template <int L>
+int launch_scl(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
+{
+    constexpr int WPB = SclCfg<L>::WPB;
+    const long long blocks = scl_blocks<L>(ctx, B);
+    if ((size_t)blocks * WPB * L * GSLOT * sizeof(double) > ctx->scl_scratch_bytes) {
+        ctx->err = "es_scl_batch: scratch slab too small for this list size"; return ES_ENOMEM;
+    }
+    SclArgs a = a0;
+    a.scratch = ctx->d_scl_scratch;
+    hipLaunchKernelGGL(es_scl_kernel<L>, dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}
+
+}  // namespace
+
+size_t es_scl_scratch_bytes(const es_ctx* ctx)
+{
+    size_t need = 0, n;
+    const int lmax = ctx->list_size_max;
+    if (lmax >= 1  && (n = scl_scratch_need<1>(ctx))  > need) need = n;
+    if (lmax >= 2  && (n = scl_scratch_need<2>(ctx))  > need) need = n;
+    if (lmax >= 4  && (n = scl_scratch_need<4>(ctx))  > need) need = n;
+    if (lmax >= 8  && (n = scl_scratch_need<8>(ctx))  > need) need = n;
+    if (lmax >= 16 && (n = scl_scratch_need<16>(ctx)) > need) need = n;
+    if (lmax >= 32 && (n = scl_scratch_need<32>(ctx)) > need) need = n;
+    return need;
+}
+
+int es_launch_scl(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
+                  uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
+                  uint8_t* cand_ok, int32_t* ncand, hipStream_t st)
+{
+    SclArgs a{};
+    a.llr = llr; a.is_f64 = (dtype == ES_DTYPE_F64); a.B = B;
+    a.frozen = ctx->frozen; a.data_pos = ctx->d_data_pos; a.exp_tab = ctx->d_exp_tab;
+    a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
+    a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
+    a.skip_if_hard_ok = skip_if_hard_ok;
+    switch (L) {
+        case 1:  return launch_scl<1>(ctx, a, B, st);
+        case 2:  return launch_scl<2>(ctx, a, B, st);
+        case 4:  return launch_scl<4>(ctx, a, B, st);
+        case 8:  return launch_scl<8>(ctx, a, B, st);
+        case 16: return launch_scl<16>(ctx, a, B, st);
+        case 32: return launch_scl<32>(ctx, a, B, st);
+        default: ctx->err = "list_size must be one of 1,2,4,8,16,32"; return ES_EINVAL;
+    }
+}
+
+int es_launch_polar_encode(es_ctx* ctx, const uint8_t* info, int64_t B, uint8_t* code, hipStream_t st)
+{
+    long long blocks = (B + 3) / 4;
+    if (blocks > (long long)ctx->num_cu * 8) blocks = (long long)ctx->num_cu * 8;
+    hipLaunchKernelGGL(es_polar_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, st, info,
+                       (long long)B, ctx->d_data_pos, code);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}

@@ -1,0 +1,212 @@
+"""RxEngine: batched EchoSeal receive hot path on one MI355X.
+
+Thin host layer over the C ABI (include/echoseal_hip.h).  torch is used only to own device
+buffers and to name the HIP stream; every computation is a hand-written HIP kernel.  Each method
+mirrors one stage of the reference detector:
+
+    bpf / xcorr / pick / sync   rtwm/detector.py:59-99   (band-pass, NCC, threshold, NMS)
+    llr                         rtwm/detector.py:296-416 (_llr)
+    scl                         rtwm/fastpolar.py:254-359 (PolarCode.decode, pre-validator)
+    polar_encode                rtwm/fastpolar.py:237-252
+
+`decode_batch` strings them together for the throughput metric: one frame record ->
+sync + LLR (variant 0, known start/counter) + SCL-L.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .tables import pack_tables
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+@dataclass
+class SclResult:
+    hard_info: torch.Tensor    # [B,55] uint8
+    hard_ok: torch.Tensor      # [B] uint8
+    cand_info: torch.Tensor    # [B,L,55] uint8, ascending metric
+    cand_metric: torch.Tensor  # [B,L] float64
+    cand_ok: torch.Tensor      # [B,L] uint8
+    ncand: torch.Tensor        # [B] int32 (0 = list loop skipped)
+
+
+@dataclass
+class SyncResult:
+    y: torch.Tensor            # [B,T] float64 band-passed records
+    corr: torch.Tensor | None  # [B,T-62] float64
+    thr: torch.Tensor          # [B] float64
+    peaks: torch.Tensor        # [B,32] int32
+    npeaks: torch.Tensor       # [B] int32 (count; bit 30 = fallback branch)
+
+
+class RxEngine:
+    def __init__(self, device: int | torch.device = 0, *, list_size_max: int = 32, fs: int = 48_000):
+        if not torch.cuda.is_available():
+            raise nat.NativeError("RxEngine needs a ROCm GPU: torch.cuda.is_available() is False")
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        self._lib = nat.load()
+        self._ctx = self._lib.es_create(self.device.index, int(list_size_max))
+        if not self._ctx:
+            raise nat.NativeError("es_create failed: " + (self._lib.es_last_error(None) or b"?").decode())
+        self.list_size_max = int(list_size_max)
+        self.fs = fs
+        ba, tpl, taps, ntaps, frozen = pack_tables(fs)
+        self._tables = (ba, tpl, taps, ntaps, frozen)       # keep host arrays alive
+        nat.check(self._ctx, self._lib.es_set_tables(
+            self._ctx, ba.ctypes.data, tpl.ctypes.data, taps.ctypes.data, ntaps.ctypes.data,
+            frozen.ctypes.data), "es_set_tables")
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            self._lib.es_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _dev(self, x, dtype) -> torch.Tensor:
+        t = torch.as_tensor(x)
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        return t.to(self.device, non_blocking=True).contiguous()
+
+    # ------------------------------------------------------------------ sync stage
+    def bpf(self, frames: torch.Tensor, band: torch.Tensor) -> torch.Tensor:
+        if frames.dim() != 2:
+            raise ValueError("frames must be [B, T]")
+        if frames.dtype == torch.int16:
+            dt = nat.ES_DTYPE_I16
+        elif frames.dtype == torch.float32:
+            dt = nat.ES_DTYPE_F32
+        else:
+            raise ValueError("frames must be float32 or int16")
+        frames = frames.contiguous()
+        B, T = frames.shape
+        y = torch.empty((B, T), dtype=torch.float64, device=self.device)
+        nat.check(self._ctx, self._lib.es_bpf_batch(self._ctx, _ptr(frames), dt, B, T, _ptr(band), _ptr(y),
+                                                    self._stream()), "es_bpf_batch")
+        return y
+
+    def xcorr(self, y: torch.Tensor, band: torch.Tensor) -> torch.Tensor:
+        B, T = y.shape
+        corr = torch.empty((B, T - 62), dtype=torch.float64, device=self.device)
+        nat.check(self._ctx, self._lib.es_xcorr_batch(self._ctx, _ptr(y), B, T, _ptr(band), _ptr(corr),
+                                                      self._stream()), "es_xcorr_batch")
+        return corr
+
+    def pick(self, corr: torch.Tensor):
+        B, n = corr.shape
+        thr = torch.empty(B, dtype=torch.float64, device=self.device)
+        peaks = torch.full((B, nat.ES_MAX_PEAKS), -1, dtype=torch.int32, device=self.device)
+        npeaks = torch.empty(B, dtype=torch.int32, device=self.device)
+        nat.check(self._ctx, self._lib.es_pick_batch(self._ctx, _ptr(corr), B, n, _ptr(thr), _ptr(peaks),
+                                                     _ptr(npeaks), self._stream()), "es_pick_batch")
+        return thr, peaks, npeaks
+
+    def sync(self, frames: torch.Tensor, band: torch.Tensor, *, keep_corr: bool = True) -> SyncResult:
+        y = self.bpf(frames, band)
+        corr = self.xcorr(y, band)
+        thr, peaks, npeaks = self.pick(corr)
+        return SyncResult(y, corr if keep_corr else None, thr, peaks, npeaks)
+
+    # ------------------------------------------------------------------ soft demod
+    def llr(self, y: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *, start: torch.Tensor | None = None,
+            variant: int = 0, want_diag: bool = False):
+        B, T = y.shape
+        out = torch.empty((B, 1024), dtype=torch.float32, device=self.device)
+        best_s = torch.empty(B, dtype=torch.int32, device=self.device) if want_diag else None
+        score = torch.empty((B, 2), dtype=torch.float32, device=self.device) if want_diag else None
+        nat.check(self._ctx, self._lib.es_llr_batch(self._ctx, _ptr(y), B, T, _ptr(start), _ptr(band), _ptr(pn_rows),
+                                                    int(variant), _ptr(out), _ptr(best_s), _ptr(score),
+                                                    self._stream()), "es_llr_batch")
+        return (out, best_s, score) if want_diag else out
+
+    # ------------------------------------------------------------------ FEC
+    def scl(self, llr: torch.Tensor, *, list_size: int = 8, skip_if_hard_ok: bool = True) -> SclResult:
+        if llr.dim() != 2 or llr.shape[1] != 1024:
+            raise ValueError("llr must be [B, 1024]")
+        if llr.dtype == torch.float32:
+            dt = nat.ES_DTYPE_F32
+        elif llr.dtype == torch.float64:
+            dt = nat.ES_DTYPE_F64
+        else:
+            raise ValueError("llr must be float32 or float64")
+        llr = llr.contiguous()
+        B, L = llr.shape[0], int(list_size)
+        dev = self.device
+        res = SclResult(
+            torch.empty((B, 55), dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.uint8, device=dev),
+            torch.zeros((B, L, 55), dtype=torch.uint8, device=dev), torch.zeros((B, L), dtype=torch.float64, device=dev),
+            torch.zeros((B, L), dtype=torch.uint8, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
+        nat.check(self._ctx, self._lib.es_scl_batch(
+            self._ctx, _ptr(llr), dt, B, L, int(bool(skip_if_hard_ok)), _ptr(res.hard_info), _ptr(res.hard_ok),
+            _ptr(res.cand_info), _ptr(res.cand_metric), _ptr(res.cand_ok), _ptr(res.ncand), self._stream()),
+            "es_scl_batch")
+        return res
+
+    def polar_encode(self, info: torch.Tensor) -> torch.Tensor:
+        info = info.contiguous()
+        B = info.shape[0]
+        code = torch.empty((B, 1024), dtype=torch.uint8, device=self.device)
+        nat.check(self._ctx, self._lib.es_polar_encode_batch(self._ctx, _ptr(info), B, _ptr(code), self._stream()),
+                  "es_polar_encode_batch")
+        return code
+
+    # ------------------------------------------------------------------ metric unit
+    def decode_batch(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *,
+                     start: torch.Tensor | None = None, list_size: int = 8, keep_corr: bool = False):
+        """sync + LLR(variant 0 at `start`, default 0) + SCL-L for every record."""
+        sy = self.sync(frames, band, keep_corr=keep_corr)
+        llr = self.llr(sy.y, band, pn_rows, start=start, variant=0)
+        scl = self.scl(llr, list_size=list_size, skip_if_hard_ok=True)
+        return sy, llr, scl
+
+
+def select_payload(scl: SclResult, row: int = 0, validator=None):
+    """Host-side tail of PolarCode.decode (rtwm/fastpolar.py:268-276, 332-359) for one record:
+    apply CRC / validator rules to the hard candidate and the metric-ordered list."""
+    hard = bytes(scl.hard_info[row].cpu().numpy().tobytes())
+    hard_ok = bool(scl.hard_ok[row].item())
+
+    def _valid(payload: bytes) -> bool:
+        try:
+            return bool(validator(payload))
+        except Exception:
+            return False
+
+    if hard_ok and (validator is None or _valid(hard)):
+        return hard, True
+    n = int(scl.ncand[row].item())
+    if n == 0:      # list loop skipped although the shortcut did not return: only when validator is set
+        raise RuntimeError("list decode was skipped; call scl(..., skip_if_hard_ok=False) when using a validator")
+    infos = scl.cand_info[row].cpu().numpy()
+    oks = scl.cand_ok[row].cpu().numpy()
+    metrics = scl.cand_metric[row].cpu().numpy()
+    best_crc = None
+    best_any = (np.inf, hard)
+    for r in range(n):
+        payload = infos[r].tobytes()
+        if oks[r]:
+            if validator is None or _valid(payload):
+                return payload, True
+            if best_crc is None or metrics[r] < best_crc[0]:
+                best_crc = (metrics[r], payload)
+        elif metrics[r] < best_any[0]:
+            best_any = (metrics[r], payload)
+    if best_crc is not None:
+        return best_crc[1], False
+    return best_any[1], False

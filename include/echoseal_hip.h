@@ -1,0 +1,130 @@
+/* echoseal_hip.h -- C ABI of libechoseal_hip.so, the MI355X (gfx950) implementation of the
+ * EchoSeal receive hot path.
+ *
+ * The reference (PetarSt98/EchoSeal) is pure Python and has no FFI layer; the boundary a
+ * maintainer would bind is therefore the set of NumPy/SciPy calls its detector makes on the hot
+ * path.  Each entry point below names the reference code it replaces.  The Python host package
+ * (echoseal_amd/, re-exported as `rtwm`) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - return value: 0 on success, negative ES_E* code on failure; es_last_error() gives text.
+ *   - "dev" pointers are device (HBM) addresses owned by the caller (e.g. torch tensors);
+ *     "host" pointers are ordinary host memory, copied during the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only enqueue
+ *     work; they never synchronise the device, so they may be captured into a hipGraph.
+ *   - one es_ctx per host thread / Python object; a context is not re-entrant.
+ */
+#ifndef ECHOSEAL_HIP_H
+#define ECHOSEAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ES_OK            0
+#define ES_EINVAL      (-1)   /* bad argument (shape, list size, null pointer) */
+#define ES_ENOTREADY   (-2)   /* tables / schedule not set */
+#define ES_EHIP        (-3)   /* a HIP runtime call failed */
+#define ES_ENOMEM      (-4)
+
+#define ES_FRAME_LEN   1215   /* 63 preamble + 128 header + 1024 payload chips (rtwm/detector.py:13-19) */
+#define ES_PRE_L         63
+#define ES_HDR_L        128
+#define ES_POLAR_N     1024
+#define ES_POLAR_K      448
+#define ES_INFO_BYTES    55
+#define ES_NBANDS         4
+#define ES_MAX_TAPS     160   /* reference taps are 93..131 long (rtwm/detector.py:260-294) */
+#define ES_MAX_PEAKS     32   /* detector consumes at most 25 peaks per scan (rtwm/detector.py:108) */
+#define ES_MAX_LIST      32
+#define ES_PN_BYTES     152   /* ceil(1215 / 8): packed PN row of one frame counter */
+
+#define ES_DTYPE_F32      0
+#define ES_DTYPE_I16      1
+#define ES_DTYPE_F64      2
+
+typedef struct es_ctx es_ctx;
+
+/* Context: binds a device, owns table / scratch memory. */
+es_ctx*     es_create(int device, int list_size_max);
+void        es_destroy(es_ctx* ctx);
+const char* es_last_error(const es_ctx* ctx);          /* ctx may be NULL (creation errors) */
+int         es_abi_version(void);
+
+/* Static per-band tables (host pointers).
+ *   ba      [4][18]  Butterworth b[9] then a[9], float64      <- rtwm/utils.py:52-55 butter_bandpass
+ *   tpl     [4][63]  unit-norm cascaded preamble template      <- rtwm/detector.py:67-69
+ *   taps    [4][ES_MAX_TAPS] float32 matched-filter taps, zero padded <- rtwm/detector.py:260-294
+ *   ntaps   [4]
+ *   frozen  [1024]   1 = frozen bit                            <- rtwm/fastpolar.py:225-226      */
+int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float* taps,
+                  const int32_t* ntaps, const uint8_t* frozen);
+
+/* Band-pass: y = lfilter(b, a, x.astype(float32)), zero initial state, float64 out.
+ *   replaces rtwm/detector.py:59-60 (and :240-241)
+ *   frames_dev [B][T] ES_DTYPE_F32 or ES_DTYPE_I16 (int16 is dequantised as x/32767)
+ *   band_dev   [B] uint8 index into the band tables
+ *   y_dev      [B][T] float64                                                               */
+int es_bpf_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
+                 const uint8_t* band_dev, double* y_dev, void* stream);
+
+/* Normalised cross-correlation with the 63-chip template:
+ *   corr[i] = sum_k y[i+k] tpl[k] / (sqrt(sum_k y[i+k]^2) + 1e-12),  i in [0, T-62)
+ *   replaces rtwm/detector.py:76-79 (np.convolve + scipy.signal.correlate)
+ *   corr_dev [B][T-62] float64                                                               */
+int es_xcorr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const uint8_t* band_dev,
+                   double* corr_dev, void* stream);
+
+/* Median/MAD threshold + non-maximum suppression (+ top-5 fallback):
+ *   replaces rtwm/detector.py:83-99
+ *   thr_dev    [B] float64
+ *   peaks_dev  [B][ES_MAX_PEAKS] int32 (ascending; fallback: descending correlation)
+ *   npeaks_dev [B] int32: number of valid entries; bit 30 set when the fallback branch ran      */
+int es_pick_batch(es_ctx* ctx, const double* corr_dev, int64_t B, int n_lags, double* thr_dev,
+                  int32_t* peaks_dev, int32_t* npeaks_dev, void* stream);
+
+/* Convenience: the three calls above back to back (workspace owned by the context). */
+int es_sync_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
+                  const uint8_t* band_dev, double* y_dev, double* corr_dev /* nullable */,
+                  double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev, void* stream);
+
+/* Soft demodulation of the payload of one frame per record:
+ *   replaces WatermarkDetector._llr (rtwm/detector.py:296-416)
+ *   y_dev      [B][T] float64 band-passed records
+ *   start_dev  [B] int32 frame start inside the record (frame = y[start : start+1215], may be short)
+ *   pn_dev     [B][ES_PN_BYTES] packed PN bits of the frame counter (MSB first)
+ *                                                       <- SecureChannel.pn_bits, rtwm/crypto.py:46-48
+ *   variant    0: payload PN = bits [191, 1215); 1: bits [0, 1024)   (rtwm/detector.py:306-312)
+ *   llr_dev    [B][1024] float32
+ *   best_s_dev [B] int32 (nullable), score_dev [B][2] float32 best / runner-up (nullable)      */
+int es_llr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const int32_t* start_dev,
+                 const uint8_t* band_dev, const uint8_t* pn_dev, int variant, float* llr_dev,
+                 int32_t* best_s_dev, float* score_dev, void* stream);
+
+/* Polar(1024,448)+CRC-8 decode: hard-decision shortcut and successive-cancellation list.
+ *   replaces PolarCode.decode (rtwm/fastpolar.py:254-359) up to validator selection
+ *   llr_dev         [B][1024] ES_DTYPE_F32 or ES_DTYPE_F64
+ *   list_size       1, 2, 4, 8, 16 or 32
+ *   skip_if_hard_ok non-zero: records whose hard decision passes CRC skip the list loop
+ *                   (the reference's behaviour when validator is None, fastpolar.py:268-276)
+ *   hard_info_dev   [B][55], hard_ok_dev [B]
+ *   cand_info_dev   [B][L][55] candidates in ascending path-metric (stable) order
+ *   cand_metric_dev [B][L] float64, cand_ok_dev [B][L] CRC flags
+ *   ncand_dev       [B] int32: L, or 0 when the list loop was skipped                         */
+int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int list_size,
+                 int skip_if_hard_ok, uint8_t* hard_info_dev, uint8_t* hard_ok_dev,
+                 uint8_t* cand_info_dev, double* cand_metric_dev, uint8_t* cand_ok_dev,
+                 int32_t* ncand_dev, void* stream);
+
+/* Polar encode (CRC-8 append, placement, butterfly): replaces PolarCode.encode
+ * (rtwm/fastpolar.py:237-252).  info_dev [B][55] packed, code_dev [B][1024] uint8 {0,1}.      */
+int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8_t* code_dev,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECHOSEAL_HIP_H */

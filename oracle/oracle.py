@@ -1,0 +1,131 @@
+"""ctypes front-end of oracle/liboracle.so (C restatement of the reference's hot path).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  The C sources (oracle/c/*.c) cite the
+reference lines they follow; tests/test_oracle_*.py pin them against vectors captured from the
+reference itself (tests/golden/, generator oracle/refshim/gen_golden.py).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, "c", f)) > os.path.getmtime(LIB)
+            for f in os.listdir(os.path.join(_HERE, "c")) if f.endswith(".c")):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "c"), "-B"], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+        _lib.eso_cfar_threshold.restype = ctypes.c_double
+        _lib.eso_sum_f32.restype = ctypes.c_float
+        _lib.eso_crc8.restype = ctypes.c_uint8
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ------------------------------------------------------------------------------- math
+def exp_vec(x): x = _c(x, np.float64); y = np.empty_like(x); lib().eso_exp_vec(_p(x), _p(y), ctypes.c_int64(x.size)); return y
+def log1p_vec(x): x = _c(x, np.float64); y = np.empty_like(x); lib().eso_log1p_vec(_p(x), _p(y), ctypes.c_int64(x.size)); return y
+def logaddexp_vec(a, b):
+    a = _c(a, np.float64); b = _c(b, np.float64); y = np.empty_like(a)
+    lib().eso_logaddexp_vec(_p(a), _p(b), _p(y), ctypes.c_int64(a.size)); return y
+def polar_f_vec(a, b):
+    a = _c(a, np.float64); b = _c(b, np.float64); y = np.empty_like(a)
+    lib().eso_polar_f_vec(_p(a), _p(b), _p(y), ctypes.c_int64(a.size)); return y
+def penalty_vec(l, bit):
+    l = _c(l, np.float64); y = np.empty_like(l)
+    lib().eso_penalty_vec(_p(l), int(bit), _p(y), ctypes.c_int64(l.size)); return y
+def sum_f32(a): a = _c(a, np.float32); return np.float32(lib().eso_sum_f32(_p(a), ctypes.c_int64(a.size)))
+
+
+# ------------------------------------------------------------------------------- polar
+def polar_tables():
+    frozen = np.zeros(1024, np.uint8); dpos = np.zeros(448, np.int32)
+    lib().eso_polar_tables(_p(frozen), _p(dpos)); return frozen.astype(bool), dpos
+
+def polar_encode(info_bits):
+    info = _c(info_bits, np.uint8); code = np.zeros(1024, np.uint8)
+    lib().eso_polar_encode(_p(info), _p(code)); return code
+
+def crc8(bits): b = _c(bits, np.uint8); return int(lib().eso_crc8(_p(b), int(b.size)))
+
+def polar_hard(llr):
+    llr = _c(llr, np.float64); info = np.zeros(440, np.uint8)
+    ok = lib().eso_polar_hard(_p(llr), _p(info)); return info, bool(ok)
+
+def scl_list(llr, L):
+    """-> (n, info[L,440], metric[L], crc[L]) in ascending-metric (stable) order."""
+    llr = _c(llr, np.float64)
+    ci = np.zeros((L, 440), np.uint8); cm = np.zeros(L); cc = np.zeros(L, np.uint8)
+    n = lib().eso_scl_list(_p(llr), int(L), _p(ci), _p(cm), _p(cc))
+    return n, ci, cm, cc
+
+def polar_decode(llr, L):
+    """PolarCode.decode(llr, validator=None) -> (info bits[440], ok, took_list)."""
+    llr = _c(llr, np.float64); info = np.zeros(440, np.uint8); tl = ctypes.c_int(0)
+    ok = lib().eso_polar_decode(_p(llr), int(L), _p(info), ctypes.byref(tl))
+    return info, bool(ok), bool(tl.value)
+
+
+# ------------------------------------------------------------------------------- DSP
+def lfilter(b, a, x):
+    b = _c(b, np.float64); a = _c(a, np.float64); x = _c(x, np.float32); y = np.empty(x.size, np.float64)
+    lib().eso_lfilter(_p(b), _p(a), int(b.size), _p(x), _p(y), ctypes.c_int64(x.size), None); return y
+
+def ncc(y, tpl):
+    y = _c(y, np.float64); tpl = _c(tpl, np.float64); out = np.empty(max(0, y.size - tpl.size + 1), np.float64)
+    lib().eso_ncc(_p(y), ctypes.c_int64(y.size), _p(tpl), int(tpl.size), _p(out)); return out
+
+def cfar_threshold(corr):
+    corr = _c(corr, np.float64); med = ctypes.c_double(); mad = ctypes.c_double()
+    thr = lib().eso_cfar_threshold(_p(corr), ctypes.c_int64(corr.size), ctypes.byref(med), ctypes.byref(mad))
+    return thr, med.value, mad.value
+
+def pick_peaks(corr, thr, min_distance=607, max_peaks=32):
+    corr = _c(corr, np.float64); pk = np.full(max_peaks, -1, np.int32); tot = ctypes.c_int(); fb = ctypes.c_int()
+    n = lib().eso_pick_peaks(_p(corr), ctypes.c_int64(corr.size), ctypes.c_double(thr), int(min_distance), _p(pk),
+                             int(max_peaks), ctypes.byref(tot), ctypes.byref(fb))
+    return pk[:n].copy(), tot.value, bool(fb.value)
+
+def llr(frame, pn_payload_bits, taps):
+    """-> (llr float32[1024], best_s, best_score, second_score)."""
+    frame = _c(frame, np.float64); pn = _c(pn_payload_bits, np.uint8); h = _c(taps, np.float32)
+    if pn.size < 1024:
+        raise ValueError("need 1024 PN bits")
+    out = np.zeros(1024, np.float32); diag = np.zeros(4)
+    lib().eso_llr(_p(frame), int(frame.size), _p(pn), _p(h), int(h.size), _p(out), _p(diag))
+    return out, int(diag[0]), float(diag[1]), float(diag[2])
+
+
+# ------------------------------------------------------------------------------- metric unit
+def decode_frame(frame_f32, ba, tpl, taps, pn_full_bits, L=8, start=0):
+    """sync + LLR(variant 0) + SCL-L for one record, as the reference would (validator None)."""
+    y = lfilter(ba[:9], ba[9:], frame_f32)
+    corr = ncc(y, tpl)
+    thr, _, _ = cfar_threshold(corr)
+    peaks, tot, fb = pick_peaks(corr, thr)
+    l, best_s, s0, s1 = llr(y[start:start + 1215], pn_full_bits[191:1215], taps)
+    info, ok, took = polar_decode(l.astype(np.float64), L)
+    return dict(y=y, corr=corr, thr=thr, peaks=peaks, npeaks=tot, fallback=fb, llr=l, best_s=best_s,
+                info=np.packbits(info).tobytes(), ok=ok, took_list=took)

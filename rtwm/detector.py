@@ -1,0 +1,3 @@
+from echoseal_amd.detector import *  # noqa: F401,F403  (drop-in alias of the reference's module name)
+from echoseal_amd import detector as _impl
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith('__')})
