@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+import torch  # noqa: F401  -- must be imported BEFORE the HIP library so that both share torch's HIP runtime
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

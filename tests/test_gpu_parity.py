@@ -1,0 +1,265 @@
+"""GPU parity: every HIP kernel, called through the C ABI (echoseal_amd.engine -> ctypes ->
+libechoseal_hip.so), against the C oracle on the same seeded inputs, against the golden vectors
+captured from the reference, and -- at BASELINE sizes -- through size-independent properties.
+
+Bars: sync offsets, thresholds, LLRs, decoded bits, path metrics are compared BIT-EXACT with the
+oracle (both implement the same fixed-order arithmetic); against the reference's golden vectors
+sync offsets / decoded bits are exact and LLRs are within 1e-5 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from echoseal_amd.embedder import WatermarkEmbedder, synthetic_payloads
+from echoseal_amd.tables import pack_tables
+from echoseal_amd.utils import band_index
+
+KEY = b"\xAA" * 32
+
+
+def _workload(B, noise=0.0, seed=3, ctr0=0):
+    tx = WatermarkEmbedder(KEY)
+    ctrs = list(range(ctr0, ctr0 + B))
+    frames = tx.make_frames(ctrs, synthetic_payloads(tx.sec, ctrs))
+    if noise:
+        frames = (frames + np.random.default_rng(seed).normal(0, noise, frames.shape)).astype(np.float32)
+    band = np.array([band_index(KEY, c) for c in ctrs], np.uint8)
+    pn = tx.sec.pn_bytes_batch(ctrs, 152)
+    return frames, band, pn
+
+
+def _dev(eng, *arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(eng.device) for a in arrs]
+
+
+def test_native_library_is_loaded(engine):
+    import echoseal_amd._native as nat
+    assert nat.load().es_abi_version() == 1
+
+
+def test_pipeline_bit_exact_vs_oracle(engine, oracle):
+    B = 96
+    frames, band, pn = _workload(B)
+    frames[B // 2:] = (frames[B // 2:] + np.random.default_rng(5).normal(0, 0.2, frames[B // 2:].shape)).astype(np.float32)
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    f, b, p = _dev(engine, frames, band, pn)
+    sy, llr, _ = engine.decode_batch(f, b, p, list_size=8, keep_corr=True)
+    res = engine.scl(llr, list_size=8, skip_if_hard_ok=False)
+    y = sy.y.cpu().numpy(); corr = sy.corr.cpu().numpy(); thr = sy.thr.cpu().numpy()
+    pk = sy.peaks.cpu().numpy(); npk = sy.npeaks.cpu().numpy(); L = llr.cpu().numpy()
+    for i in range(B):
+        bi = band[i]
+        o = oracle.decode_frame(frames[i], ba[bi], tpl[bi], taps[bi, :ntaps[bi]], np.unpackbits(pn[i])[:1215], L=8)
+        assert np.array_equal(o["y"], y[i]) and np.array_equal(o["corr"], corr[i]) and o["thr"] == thr[i]
+        n = int(npk[i]) & 0xFFFF
+        assert n == min(o["npeaks"], 32) and bool(npk[i] >> 30) == o["fallback"]
+        assert list(o["peaks"][:n]) == list(pk[i, :n])
+        assert np.array_equal(o["llr"], L[i])
+        hinfo, hok = oracle.polar_hard(L[i].astype(np.float64))
+        assert np.packbits(hinfo).tobytes() == res.hard_info[i].cpu().numpy().tobytes() and hok == bool(res.hard_ok[i])
+        nn, ci, cm, cc = oracle.scl_list(L[i].astype(np.float64), 8)
+        assert np.array_equal(np.packbits(ci, axis=1), res.cand_info[i].cpu().numpy())
+        assert np.array_equal(cm, res.cand_metric[i].cpu().numpy())
+        assert np.array_equal(cc, res.cand_ok[i].cpu().numpy())
+
+
+@pytest.mark.parametrize("L", [1, 2, 4, 8, 16, 32])
+def test_scl_all_list_sizes_vs_oracle(engine, oracle, L):
+    rng = np.random.default_rng(100 + L)
+    llr = np.clip(rng.normal(0, 3, (12, 1024)), -12, 12)
+    llr[0] = 0.0; llr[0, 0] = 1e-3                                       # every candidate ties
+    llr[1] = np.where(rng.integers(0, 2, 1024) == 1, 12.0, -12.0)        # saturated, many exact ties
+    llr[2] = rng.normal(0, 3000, 1024)                                   # exp underflow / subnormals
+    for dt in (np.float64, np.float32):
+        x = llr.astype(dt)
+        res = engine.scl(torch.from_numpy(x).to(engine.device), list_size=L, skip_if_hard_ok=False)
+        for i in range(x.shape[0]):
+            nn, ci, cm, cc = oracle.scl_list(x[i].astype(np.float64), L)
+            assert int(res.ncand[i]) == nn == L
+            assert np.array_equal(np.packbits(ci, axis=1), res.cand_info[i].cpu().numpy()), (L, i)
+            assert np.array_equal(cm, res.cand_metric[i].cpu().numpy()), (L, i)
+            assert np.array_equal(cc, res.cand_ok[i].cpu().numpy()), (L, i)
+
+
+def test_scl_matches_reference_golden(engine, golden_polar):
+    from echoseal_amd.engine import select_payload
+    mode, g = golden_polar
+    names = sorted({k.split("/")[0] for k in g.files if k.endswith("/llr")})
+    for L in (1, 4, 8, 16, 32):
+        llrs = [g[f"{n}/llr"] for n in names]
+        for dt in (np.float32, np.float64):
+            idx = [i for i, v in enumerate(llrs) if v.dtype == dt]
+            if not idx:
+                continue
+            x = torch.from_numpy(np.stack([llrs[i] for i in idx])).to(engine.device)
+            res = engine.scl(x, list_size=L, skip_if_hard_ok=True)
+            for row, i in enumerate(idx):
+                payload, ok = select_payload(res, row, None)
+                assert ok == bool(g[f"{names[i]}/L{L}/ok"]), (names[i], L)
+                assert payload == g[f"{names[i]}/L{L}/info"].tobytes(), (names[i], L)      # decoded bits: exact
+                key = f"{names[i]}/L{L}/cand_metric"
+                if key in g.files:
+                    assert int(res.ncand[row]) == L
+                    assert np.array_equal(res.cand_info[row].cpu().numpy(), g[f"{names[i]}/L{L}/cand_info"])
+                    m = res.cand_metric[row].cpu().numpy()
+                    if mode == "glibc":
+                        assert np.array_equal(m, g[key])
+                    else:
+                        assert np.allclose(m, g[key], rtol=1e-13, atol=0)
+                else:
+                    assert int(res.ncand[row]) == 0
+
+
+def test_sync_and_llr_match_reference_golden(engine, golden_detector):
+    g = golden_detector
+    n = int(g["det/count"])
+    tags = [f"det/{i:02d}" for i in range(n)]
+    x = np.stack([g[f"{t}/x"] for t in tags]); band = np.array([int(g[f"{t}/band"]) for t in tags], np.uint8)
+    pn = np.zeros((n, 152), np.uint8); pn[:, :] = np.stack([g[f"{t}/pn"] for t in tags])
+    f, b, p = _dev(engine, x, band, pn)
+    sy = engine.sync(f, b)
+    llr0, bs0, _ = engine.llr(sy.y, b, p, variant=0, want_diag=True)
+    llr1, bs1, _ = engine.llr(sy.y, b, p, variant=1, want_diag=True)
+    y = sy.y.cpu().numpy(); corr = sy.corr.cpu().numpy(); thr = sy.thr.cpu().numpy()
+    pk = sy.peaks.cpu().numpy(); npk = sy.npeaks.cpu().numpy()
+    worst = 0.0
+    for i, t in enumerate(tags):
+        assert np.array_equal(y[i], g[f"{t}/y"])                                  # IIR: bit exact
+        assert np.max(np.abs(corr[i] - g[f"{t}/corr"])) < 1e-12
+        assert abs(thr[i] - float(g[f"{t}/thr"])) < 1e-12
+        k = int(npk[i]) & 0xFFFF
+        assert list(pk[i, :k]) == list(g[f"{t}/peaks"]) and bool(npk[i] >> 30) == bool(g[f"{t}/fallback"])
+        assert int(bs0[i]) == int(g[f"{t}/best_s"][0]) and int(bs1[i]) == int(g[f"{t}/best_s"][1])
+        worst = max(worst, float(np.max(np.abs(llr0[i].cpu().numpy() - g[f"{t}/llr0"]))),
+                    float(np.max(np.abs(llr1[i].cpu().numpy() - g[f"{t}/llr1"]))))
+    assert worst <= 1e-5, worst
+    # short records: frame = y[:700] -> zero padded LLR (rtwm/detector.py:410-414)
+    ys = sy.y[:, :700].contiguous()
+    ls, bss, _ = engine.llr(ys, b, p, variant=0, want_diag=True)
+    for i, t in enumerate(tags):
+        assert int(bss[i]) == int(g[f"{t}/best_s"][2])
+        assert np.max(np.abs(ls[i].cpu().numpy() - g[f"{t}/llr_short700"])) <= 1e-5
+
+
+def test_edge_records(engine, oracle):
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    rng = np.random.default_rng(8)
+    # ragged tail (batch not a multiple of 64), window longer than a frame, silence, constants, int16
+    for T in (63, 64, 700, 1215, 2048):
+        x = rng.normal(0, 0.1, (5, T)).astype(np.float32)
+        x[1] = 0.0
+        x[2] = 0.25
+        band = np.array([0, 1, 2, 3, 1], np.uint8)
+        f, b = _dev(engine, x, band)
+        sy = engine.sync(f, b)
+        for i in range(5):
+            y = oracle.lfilter(ba[band[i], :9], ba[band[i], 9:], x[i])
+            assert np.array_equal(y, sy.y[i].cpu().numpy())
+            corr = oracle.ncc(y, tpl[band[i]])
+            assert np.array_equal(corr, sy.corr[i].cpu().numpy())
+            thr, _, _ = oracle.cfar_threshold(corr)
+            assert thr == float(sy.thr[i])
+            peaks, tot, fb = oracle.pick_peaks(corr, thr)
+            if i == 1:
+                continue                     # all-zero correlation: every lag ties (declared ambiguous)
+            k = int(sy.npeaks[i]) & 0xFFFF
+            assert bool(int(sy.npeaks[i]) >> 30) == fb and list(sy.peaks[i, :k].cpu().numpy()) == list(peaks[:k])
+    xi = np.clip(np.round(rng.normal(0, 0.2, (3, 1215)) * 32767), -32767, 32767).astype(np.int16)
+    band = np.array([3, 0, 2], np.uint8)
+    f, b = _dev(engine, xi, band)
+    yi = engine.bpf(f, b).cpu().numpy()
+    for i in range(3):
+        xf = (xi[i].astype(np.float32) / np.float32(32767))
+        assert np.array_equal(yi[i], oracle.lfilter(ba[band[i], :9], ba[band[i], 9:], xf))
+    # frames starting inside a longer window, including one that runs off the end
+    frames, bnd, pn = _workload(4)
+    win = np.zeros((4, 2048), np.float32); starts = np.array([0, 100, 833, 1500], np.int32)
+    for i in range(4):
+        seg = frames[i][: 2048 - starts[i]]
+        win[i, starts[i]:starts[i] + seg.size] = seg
+    f, b, p, s = _dev(engine, win, bnd, pn, starts)
+    y = engine.bpf(f, b)
+    llr, bs, _ = engine.llr(y, b, p, start=s, want_diag=True)
+    for i in range(4):
+        yy = y[i].cpu().numpy()
+        o, obs, _, _ = oracle.llr(yy[starts[i]:starts[i] + 1215], np.unpackbits(pn[i])[191:1215], taps[bnd[i], :ntaps[bnd[i]]])
+        assert obs == int(bs[i]) and np.array_equal(o, llr[i].cpu().numpy())
+    # empty batch and argument errors
+    e = torch.empty((0, 1024), dtype=torch.float32, device=engine.device)
+    assert engine.scl(e, list_size=8).ncand.numel() == 0
+    from echoseal_amd._native import NativeError
+    with pytest.raises(NativeError):
+        engine.scl(torch.zeros((1, 1024), device=engine.device), list_size=3)
+    with pytest.raises(NativeError):
+        engine.scl(torch.zeros((1, 1024), device=engine.device), list_size=64)
+
+
+def test_polar_encode_kernel(engine, oracle):
+    rng = np.random.default_rng(9)
+    info = rng.integers(0, 256, (37, 55), dtype=np.uint8)
+    code = engine.polar_encode(torch.from_numpy(info).to(engine.device)).cpu().numpy()
+    for i in range(37):
+        assert np.array_equal(code[i], oracle.polar_encode(np.unpackbits(info[i])))
+
+
+def test_full_size_properties(engine, oracle):
+    """BASELINE config 2 (1 024 clean frames) and a 65 536-record batch: size-independent checks.
+    encode -> +-LLR -> decode round trip; sync finds offset 0 on every clean frame; a spot-checked
+    subset equals the oracle bit for bit; results do not depend on batch position."""
+    B = 1024
+    frames, band, pn = _workload(B)
+    f, b, p = _dev(engine, frames, band, pn)
+    sy, llr, scl = engine.decode_batch(f, b, p, list_size=8)
+    npk = sy.npeaks.cpu().numpy(); pk = sy.peaks.cpu().numpy()
+    # every clean frame syncs at offset 0 (a few also show a second >0.95 peak further than 607 lags away)
+    assert np.all(npk >= 1) and np.all(npk < 4) and np.all(pk[:, 0] == 0) and np.all(sy.thr.cpu().numpy() == 0.95)
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    L = llr.cpu().numpy()
+    for i in range(0, B, 97):
+        o = oracle.decode_frame(frames[i], ba[band[i]], tpl[band[i]], taps[band[i], :ntaps[band[i]]],
+                                np.unpackbits(pn[i])[:1215], L=8)
+        assert np.array_equal(o["llr"], L[i])
+        nn, ci, cm, cc = oracle.scl_list(L[i].astype(np.float64), 8)
+        if int(scl.ncand[i]):
+            assert np.array_equal(np.packbits(ci, axis=1), scl.cand_info[i].cpu().numpy())
+            assert np.array_equal(cm, scl.cand_metric[i].cpu().numpy())
+    # round trip at scale: random payloads -> GPU encode -> +-4 LLR with 3 % flips -> SCL-8
+    rng = np.random.default_rng(77)
+    Bb = 65536
+    info = torch.from_numpy(rng.integers(0, 256, (Bb, 55), dtype=np.uint8)).to(engine.device)
+    code = engine.polar_encode(info)
+    soft = (code.to(torch.float32) * 2 - 1) * 4.0
+    res = engine.scl(soft, list_size=8, skip_if_hard_ok=True)
+    assert bool(torch.all(res.hard_ok == 1)) and bool(torch.all(res.hard_info == info))
+    # batch-position independence: the same 64 LLR rows at the start and the end of a big batch
+    big = soft.clone()
+    noise = torch.from_numpy(rng.normal(0, 5, (64, 1024)).astype(np.float32)).to(engine.device)
+    big[:64] = noise; big[-64:] = noise
+    r2 = engine.scl(big, list_size=8, skip_if_hard_ok=True)
+    assert bool(torch.all(r2.cand_info[:64] == r2.cand_info[-64:])) and bool(torch.all(r2.cand_metric[:64] == r2.cand_metric[-64:]))
+    assert bool(torch.all(r2.ncand[:64] == r2.ncand[-64:]))
+
+
+def test_polarcode_api_on_gpu(golden_polar):
+    """Reference-style calls (tests/test_polar.py of the reference) through the drop-in API."""
+    from rtwm.polar_fast import decode, encode, N_DEFAULT, K_DEFAULT
+    from rtwm.fastpolar import PolarCode
+    _, g = golden_polar
+    payload = bytes(range(55))
+    chips = encode(payload)
+    assert decode(np.where(chips == 1, 10.0, -10.0).astype(np.float32)) == payload
+    rng = np.random.default_rng(1234)
+    pc = PolarCode(N_DEFAULT, K_DEFAULT, list_size=8, crc_size=8)
+    info = rng.integers(0, 2, 440, dtype=np.uint8)
+    cw = pc.encode(info)
+    rx = 2.0 * cw.astype(np.float64) - 1.0 + rng.normal(0.0, 0.15, 1024)
+    bits, ok = pc.decode(2.0 * rx / 0.15 ** 2)
+    assert ok and np.array_equal(bits, info)
+    # validator that rejects everything: reference returns the best CRC-passing (or lowest-metric) path, ok False
+    out, ok = decode(g["garbage_rng7/llr"], list_size=8, return_ok=True, validator=lambda b: False)
+    assert ok is False and len(out) == 55
+    with pytest.raises(ValueError):
+        decode(np.zeros(1000))
+    with pytest.raises(ValueError):
+        encode(b"short")

@@ -1,0 +1,102 @@
+"""CPU-side checks: the drop-in package surface, the embedder restatement against frames captured
+from the reference, and that the C-ABI library exports what include/echoseal_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_and_library_agree():
+    import echoseal_amd._native as nat
+    hdr = open(os.path.join(ROOT, "include", "echoseal_hip.h")).read()
+    declared = set(re.findall(r"\b(es_[a-z0-9_]+)\s*\(", hdr)) - {"es_ctx"}
+    assert declared == set(nat.SIGNATURES), declared ^ set(nat.SIGNATURES)
+    assert os.path.exists(nat.LIB_PATH), "build the HIP library first (__graft_entry__.build())"
+    lib = ctypes.CDLL(nat.LIB_PATH)                       # loads without a GPU; no compute calls here
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.es_abi_version() == 1
+    for const, val in (("ES_FRAME_LEN", 1215), ("ES_MAX_TAPS", 160), ("ES_MAX_PEAKS", 32), ("ES_PN_BYTES", 152)):
+        assert int(re.search(rf"#define\s+{const}\s+(\d+)", hdr).group(1)) == val == getattr(nat, const)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "echoseal_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_dropin_surface():
+    import rtwm
+    from rtwm.detector import (WatermarkDetector, mseq_63, FRAME_LEN, PRE_L, HDR_L, PRE_BITS, HDR_BITS, HDR_REPEAT,
+                               TIGHT_DELTA, WIDE_DELTA, EPS, BAND_PLAN, choose_band, butter_bandpass, resample_to, N_DEFAULT)
+    from rtwm.embedder import WatermarkEmbedder, TxParams
+    from rtwm.polar_fast import N_DEFAULT as N2, K_DEFAULT, encode, decode
+    from rtwm.utils import lin_to_db, db_to_lin
+    from rtwm.fastpolar import PolarCode
+    from rtwm.reliability_polar_bits import Q_Nmax
+    assert (FRAME_LEN, PRE_L, HDR_L, HDR_BITS, HDR_REPEAT, TIGHT_DELTA, WIDE_DELTA) == (1215, 63, 128, 16, 8, 3, 200)
+    assert N_DEFAULT == N2 == 1024 and K_DEFAULT == 448 and len(Q_Nmax.split()) == 1024
+    assert rtwm.WatermarkDetector is WatermarkDetector
+    with pytest.raises(ValueError):
+        WatermarkDetector(b"short")
+    for bad in (dict(N=1000, K=448), dict(N=1024, K=0), dict(N=1024, K=448, list_size=0), dict(N=1024, K=448, crc_size=448)):
+        with pytest.raises(ValueError):
+            PolarCode(**bad)
+    pc = PolarCode(1024, 448)
+    assert pc._info_len == 440 and pc.frozen.sum() == 576 and pc._data_pos[0] == 0
+    with pytest.raises(ValueError):
+        pc.encode(np.zeros(100, np.uint8))
+    with pytest.raises(ValueError):
+        encode(b"x" * 54)
+    assert abs(db_to_lin(lin_to_db(0.5)) - 0.5) < 1e-9
+
+
+def test_embedder_reproduces_reference_frames(golden_detector):
+    """Clean frames in the fixture were produced by the reference's embedder with a fixed payload."""
+    from echoseal_amd.embedder import WatermarkEmbedder
+    g = golden_detector
+    seen = 0
+    for i in range(int(g["det/count"])):
+        t = f"det/{i:02d}"
+        key = g[f"{t}/key"].tobytes(); ctr = int(g[f"{t}/ctr"])
+        mine = WatermarkEmbedder(key).make_frames([ctr], [g[f"{t}/payload"].tobytes()])[0]
+        ref = g[f"{t}/x"]
+        if np.array_equal(mine, ref):
+            seen += 1
+        else:                                             # noisy variants carry added AWGN
+            assert np.std(mine - ref) > 0.1
+    assert seen >= 14
+
+
+def test_embedder_alignment_like_reference_test():
+    """Mirror of the reference's tests/test_embedder_detector_alignment.py:22-33."""
+    from rtwm.embedder import WatermarkEmbedder
+    from rtwm.detector import WatermarkDetector, FRAME_LEN, PRE_L, HDR_L
+    key = bytes(32)
+    tx = WatermarkEmbedder(key)
+    try:
+        rx = WatermarkDetector(key)
+    except Exception as e:                                # needs the GPU engine only lazily
+        pytest.fail(f"constructing the detector must not need a GPU: {e}")
+    np.testing.assert_allclose(tx._preamble_sy, rx._pre_sy)
+    np.testing.assert_allclose(tx._hdr_pn_sy, rx._hdr_pn_sy)
+    for ctr in (0, 1, 255, 1024):
+        assert np.array_equal(tx.sec.pn_bits(ctr, PRE_L + HDR_L + tx.p.N), rx.sec.pn_bits(ctr, FRAME_LEN))
+    assert tx.process(np.zeros(3000, np.float32)).shape == (3000,)
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rtwm.polar_fast import decode
+    from echoseal_amd._native import NativeError
+    with pytest.raises(NativeError):
+        decode(np.ones(1024))
