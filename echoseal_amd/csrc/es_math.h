@@ -119,7 +119,8 @@ ES_HD double es_log1p(double x)
     const int32_t hx = es_hi32(x);
     const int32_t ax = hx & 0x7fffffff;
     int32_t k = 1, hu = 0;
-    double f = 0.0, c = 0.0;
+    double f = 0.0;
+    double cn = 0.0, cd = 1.0;                        /* correction term c = cn / cd */
 
     if (hx < 0x3FDA827A) {                            /* x < sqrt(2)-1 */
         if (ax >= 0x3ff00000) {                       /* x <= -1: not used by the decoder */
@@ -142,13 +143,12 @@ ES_HD double es_log1p(double x)
             u = 1.0 + x;
             hu = es_hi32(u);
             k = (hu >> 20) - 1023;
-            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
-            c = c / u;
+            cn = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+            cd = u;
         } else {
             u = x;
             hu = es_hi32(u);
             k = (hu >> 20) - 1023;
-            c = 0.0;
         }
         hu &= 0x000fffff;
         if (hu < 0x6a09e) {
@@ -160,6 +160,9 @@ ES_HD double es_log1p(double x)
         }
         f = u - 1.0;
     }
+    /* fdlibm divides right where c is formed; dividing here instead (0/1 when k == 0) yields the
+       same correctly rounded quotient and lets this division overlap the one for s below. */
+    double c = cn / cd;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     if (hu == 0) {                                    /* |f| < 2^-20 */
@@ -189,19 +192,264 @@ ES_HD double es_log1p(double x)
 /* ---- numpy's logaddexp inner loop (npymath npy_logaddexp) --------------------------------- */
 #define ES_LOGE2 0.693147180559945309417232121458176568
 
-ES_HD double es_logaddexp(double x, double y, const uint64_t* tab)
+/* softplus of a non-positive argument: log1p(exp(t)), t = -|d|  -- generic (branchy) form */
+ES_HD double es_softplus_neg_generic(double t, const uint64_t* tab) { return es_log1p(es_exp(t, tab)); }
+
+/* Straight-line (branch-free) evaluation of the same value for the common range
+ *     2^-54 <= |t| < 512  and  log1p not in its |f| < 2^-20 corner,
+ * i.e. es_exp's main path followed by es_log1p's tiny / k==0 / k!=0 paths merged with selects.
+ * Every arithmetic step is the one the generic functions perform for that input, so the result is
+ * bit-identical; *ok = 0 flags inputs outside that range (caller falls back to the generic form).
+ * Having no control flow lets the compiler interleave several independent evaluations, which is
+ * what hides the ~1.3 k-cycle dependent latency of one evaluation on a single wavefront. */
+ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
 {
-    if (x == y) return x + ES_LOGE2;
-    const double d = x - y;
-    if (d > 0) return x + es_log1p(es_exp(-d, tab));
-    if (d <= 0) return y + es_log1p(es_exp(d, tab));
-    return d;                                         /* nan */
+    /* ---- exp(t), main path of es_exp ---- */
+    const uint64_t xb = es_d2u(t);
+    const uint32_t abstop = (uint32_t)(xb >> 52) & 0x7ffu;
+    const int exp_main = (abstop - 0x3c9u) < 0x3fu;
+    double kd = ES_FMA(t, ES_EXP_INVLN2N, ES_EXP_SHIFT);
+    const uint64_t ki = es_d2u(kd);
+    kd = kd - ES_EXP_SHIFT;
+    double r = ES_FMA(kd, ES_EXP_NLN2HI, t);
+    r = ES_FMA(kd, ES_EXP_NLN2LO, r);
+    const uint32_t idx = 2u * (uint32_t)(ki & 127u);
+    const double tail = es_u2d(tab[idx]);
+    const uint64_t sbits = tab[idx + 1] + (ki << 45);
+    const double p23 = ES_FMA(r, ES_EXP_C3, ES_EXP_C2);
+    const double tr = r + tail;
+    const double r2 = r * r;
+    const double p45 = ES_FMA(r, ES_EXP_C5, ES_EXP_C4);
+    const double tq = ES_FMA(p23, r2, tr);
+    const double r4 = r2 * r2;
+    const double tmp = ES_FMA(r4, p45, tq);
+    const double scale = es_u2d(sbits);
+    const double y = ES_FMA(scale, tmp, scale);           /* in (0, 1) */
+
+    /* ---- log1p(y) ---- */
+    const int32_t hy = es_hi32(y);
+    const int tiny54 = hy < 0x3c900000;                   /* y < 2^-54  -> y            */
+    const int tiny29 = hy < 0x3e200000;                   /* y < 2^-29  -> y - y*y/2    */
+    const int k0 = hy < 0x3FDA827A;                       /* y < sqrt(2)-1: k = 0, f = y */
+    const double u = 1.0 + y;
+    const int32_t hu0 = es_hi32(u);
+    const int32_t kk = (hu0 >> 20) - 1023;
+    const double cn1 = (kk > 0) ? 1.0 - (u - y) : y - (u - 1.0);
+    const int32_t hum = hu0 & 0x000fffff;
+    const int big = hum >= 0x6a09e;
+    const int32_t k1 = kk + (big ? 1 : 0);
+    const uint32_t newhi = (uint32_t)(hum | (big ? 0x3fe00000 : 0x3ff00000));
+    const double un = es_u2d((es_d2u(u) & 0xffffffffULL) | ((uint64_t)newhi << 32));
+    const int32_t hu1 = big ? ((0x00100000 - hum) >> 2) : hum;
+    const double f = k0 ? y : un - 1.0;
+    const int32_t k = k0 ? 0 : k1;
+    const int32_t hu = k0 ? 1 : hu1;
+    const double c = (k0 ? 0.0 : cn1) / (k0 ? 1.0 : u);
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R1 = z * ES_LP1;
+    const double z2 = z * z;
+    const double R2 = ES_LP2 + z * ES_LP3;
+    const double z4 = z2 * z2;
+    const double R3 = ES_LP4 + z * ES_LP5;
+    const double z6 = z4 * z2;
+    const double R4 = ES_LP6 + z * ES_LP7;
+    const double R = ((R1 + z2 * R2) + z4 * R3) + z6 * R4;
+    const double sR = s * (hfsq + R);
+    const double res0 = f - (hfsq - sR);
+    const double resk = dk * ES_LN2_HI - ((hfsq - (sR + (dk * ES_LN2_LO + c))) - f);
+    double res = (k == 0) ? res0 : resk;
+    const double rt = y - y * y * 0.5;
+    res = tiny29 ? rt : res;
+    res = tiny54 ? y : res;
+    *ok = exp_main && (tiny29 || hu != 0);
+    return res;
 }
 
-/* rtwm/fastpolar.py:18-23  _f_function */
+ES_HD double es_softplus_neg(double t, const uint64_t* tab)
+{
+    int ok;
+    double r = es_softplus_neg_fast(t, tab, &ok);
+    if (!ok) r = es_softplus_neg_generic(t, tab);
+    return r;
+}
+
+/* Branch-free form of npy_logaddexp (identical values: for d > 0 the reference evaluates
+ * x + log1p(exp(-d)), otherwise y + log1p(exp(d)); x == y short-circuits to x + ln 2).  Lanes of
+ * a wavefront disagree on the sign of d all the time, so the two-branch form would run exp/log1p
+ * twice.  *sp receives log1p(exp(-|x-y|)), which the decoder reuses as a path-metric penalty. */
+ES_HD double es_logaddexp_sp(double x, double y, const uint64_t* tab, double* sp)
+{
+    const double d = x - y;
+    const int pos = d > 0;
+    const double t = pos ? -d : d;
+    const double L = es_softplus_neg(t, tab);
+    *sp = L;
+    double r = (pos ? x : y) + L;
+    if (x == y) r = x + ES_LOGE2;
+    return r;
+}
+
+ES_HD double es_logaddexp(double x, double y, const uint64_t* tab)
+{
+    double sp;
+    return es_logaddexp_sp(x, y, tab, &sp);
+}
+
+/* rtwm/fastpolar.py:18-23  _f_function; also returns the two softplus terms
+ *   *sp_diff = log1p(exp(-|a-b|)),  *sp_sum = log1p(exp(-|a+b|))
+ * which are exactly the penalties log1p(exp(-|g|)) of the sibling leaf g = b -/+ a. */
+ES_HD double es_polar_f_sp(double a, double b, const uint64_t* tab, double* sp_diff, double* sp_sum)
+{
+    /* two independent softplus evaluations, written out so that they can be interleaved */
+    const double d1 = a - b;
+    const int pos1 = d1 > 0;
+    const double sum = a + b;
+    const double d2 = 0.0 - sum;
+    const int pos2 = d2 > 0;
+    const double t1 = pos1 ? -d1 : d1;
+    const double t2 = pos2 ? -d2 : d2;
+    int ok1, ok2;
+    double L1 = es_softplus_neg_fast(t1, tab, &ok1);
+    double L2 = es_softplus_neg_fast(t2, tab, &ok2);
+    if (!ok1) L1 = es_softplus_neg_generic(t1, tab);
+    if (!ok2) L2 = es_softplus_neg_generic(t2, tab);
+    *sp_diff = L1;
+    *sp_sum = L2;
+    double r1 = (pos1 ? a : b) + L1;                     /* logaddexp(a, b)     */
+    if (a == b) r1 = a + ES_LOGE2;
+    double r2 = (pos2 ? 0.0 : sum) + L2;                 /* logaddexp(0, a + b) */
+    if (0.0 == sum) r2 = 0.0 + ES_LOGE2;
+    return r1 - r2;
+}
+
+#ifdef __cplusplus
+/* W independent softplus evaluations with every step written W-wide, so that the instruction
+ * stream alternates between the chains and their dependent latencies overlap (the AMDGPU scheduler
+ * keeps source order for independent operations).  Same arithmetic as es_softplus_neg_fast. */
+template <int W>
+ES_HD void es_softplus_neg_fastN(const double (&t)[W], const uint64_t* tab, double (&out)[W], int (&ok)[W])
+{
+    double kd[W], r[W], tail[W], scale[W], y[W], u[W], f[W], c[W], hfsq[W], dk[W], s[W], z[W], R[W];
+    uint64_t ki[W], sbits[W];
+    int exp_main[W], tiny54[W], tiny29[W], k0[W], k[W], hu[W];
+    #define ES_W for (int e = 0; e < W; ++e)
+    #pragma unroll
+    ES_W { exp_main[e] = (((uint32_t)(es_d2u(t[e]) >> 52) & 0x7ffu) - 0x3c9u) < 0x3fu; }
+    #pragma unroll
+    ES_W { kd[e] = ES_FMA(t[e], ES_EXP_INVLN2N, ES_EXP_SHIFT); }
+    #pragma unroll
+    ES_W { ki[e] = es_d2u(kd[e]); kd[e] = kd[e] - ES_EXP_SHIFT; }
+    #pragma unroll
+    ES_W { const uint32_t idx = 2u * (uint32_t)(ki[e] & 127u); tail[e] = es_u2d(tab[idx]); sbits[e] = tab[idx + 1] + (ki[e] << 45); }
+    #pragma unroll
+    ES_W { r[e] = ES_FMA(kd[e], ES_EXP_NLN2HI, t[e]); }
+    #pragma unroll
+    ES_W { r[e] = ES_FMA(kd[e], ES_EXP_NLN2LO, r[e]); }
+    double p23[W], tr[W], r2[W], p45[W];
+    #pragma unroll
+    ES_W { p23[e] = ES_FMA(r[e], ES_EXP_C3, ES_EXP_C2); }
+    #pragma unroll
+    ES_W { tr[e] = r[e] + tail[e]; }
+    #pragma unroll
+    ES_W { r2[e] = r[e] * r[e]; }
+    #pragma unroll
+    ES_W { p45[e] = ES_FMA(r[e], ES_EXP_C5, ES_EXP_C4); }
+    #pragma unroll
+    ES_W { tr[e] = ES_FMA(p23[e], r2[e], tr[e]); }
+    #pragma unroll
+    ES_W { r2[e] = r2[e] * r2[e]; }
+    #pragma unroll
+    ES_W { tr[e] = ES_FMA(r2[e], p45[e], tr[e]); }
+    #pragma unroll
+    ES_W { scale[e] = es_u2d(sbits[e]); y[e] = ES_FMA(scale[e], tr[e], scale[e]); }
+    /* log1p */
+    double cn[W], cd[W];
+    #pragma unroll
+    ES_W { const int32_t hy = es_hi32(y[e]); tiny54[e] = hy < 0x3c900000; tiny29[e] = hy < 0x3e200000; k0[e] = hy < 0x3FDA827A; }
+    #pragma unroll
+    ES_W { u[e] = 1.0 + y[e]; }
+    #pragma unroll
+    ES_W {
+        const int32_t hu0 = es_hi32(u[e]);
+        const int32_t kk = (hu0 >> 20) - 1023;
+        const double cn1 = (kk > 0) ? 1.0 - (u[e] - y[e]) : y[e] - (u[e] - 1.0);
+        const int32_t hum = hu0 & 0x000fffff;
+        const int big = hum >= 0x6a09e;
+        const int32_t k1 = kk + (big ? 1 : 0);
+        const uint32_t newhi = (uint32_t)(hum | (big ? 0x3fe00000 : 0x3ff00000));
+        const double un = es_u2d((es_d2u(u[e]) & 0xffffffffULL) | ((uint64_t)newhi << 32));
+        const int32_t hu1 = big ? ((0x00100000 - hum) >> 2) : hum;
+        f[e] = k0[e] ? y[e] : un - 1.0;
+        k[e] = k0[e] ? 0 : k1;
+        hu[e] = k0[e] ? 1 : hu1;
+        cn[e] = k0[e] ? 0.0 : cn1;
+        cd[e] = k0[e] ? 1.0 : u[e];
+    }
+    double den[W];
+    #pragma unroll
+    ES_W { den[e] = 2.0 + f[e]; hfsq[e] = 0.5 * f[e] * f[e]; dk[e] = (double)k[e]; }
+    #pragma unroll
+    ES_W { c[e] = cn[e] / cd[e]; }
+    #pragma unroll
+    ES_W { s[e] = f[e] / den[e]; }
+    #pragma unroll
+    ES_W { z[e] = s[e] * s[e]; }
+    double z2[W], R1[W], R2[W], R3[W], R4[W], z4[W], z6[W];
+    #pragma unroll
+    ES_W { R1[e] = z[e] * ES_LP1; z2[e] = z[e] * z[e]; R2[e] = ES_LP2 + z[e] * ES_LP3; R3[e] = ES_LP4 + z[e] * ES_LP5; R4[e] = ES_LP6 + z[e] * ES_LP7; }
+    #pragma unroll
+    ES_W { z4[e] = z2[e] * z2[e]; }
+    #pragma unroll
+    ES_W { z6[e] = z4[e] * z2[e]; }
+    #pragma unroll
+    ES_W { R[e] = ((R1[e] + z2[e] * R2[e]) + z4[e] * R3[e]) + z6[e] * R4[e]; }
+    #pragma unroll
+    ES_W {
+        const double sR = s[e] * (hfsq[e] + R[e]);
+        const double res0 = f[e] - (hfsq[e] - sR);
+        const double resk = dk[e] * ES_LN2_HI - ((hfsq[e] - (sR + (dk[e] * ES_LN2_LO + c[e]))) - f[e]);
+        double res = (k[e] == 0) ? res0 : resk;
+        const double rt = y[e] - y[e] * y[e] * 0.5;
+        res = tiny29[e] ? rt : res;
+        res = tiny54[e] ? y[e] : res;
+        out[e] = res;
+        ok[e] = exp_main[e] && (tiny29[e] || hu[e] != 0);
+    }
+    #undef ES_W
+}
+
+/* W independent f evaluations (2W interleaved softplus chains). */
+template <int W>
+ES_HD void es_polar_fN(const double (&a)[W], const double (&b)[W], const uint64_t* tab, double (&out)[W])
+{
+    double t[2 * W], L[2 * W], sum[W]; int ok[2 * W], pos1[W], pos2[W];
+    #pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const double d1 = a[e] - b[e]; pos1[e] = d1 > 0; t[2 * e] = pos1[e] ? -d1 : d1;
+        sum[e] = a[e] + b[e];
+        const double d2 = 0.0 - sum[e]; pos2[e] = d2 > 0; t[2 * e + 1] = pos2[e] ? -d2 : d2;
+    }
+    es_softplus_neg_fastN<2 * W>(t, tab, L, ok);
+    #pragma unroll
+    for (int e = 0; e < 2 * W; ++e) if (!ok[e]) L[e] = es_softplus_neg_generic(t[e], tab);
+    #pragma unroll
+    for (int e = 0; e < W; ++e) {
+        double r1 = (pos1[e] ? a[e] : b[e]) + L[2 * e];
+        if (a[e] == b[e]) r1 = a[e] + ES_LOGE2;
+        double r2 = (pos2[e] ? 0.0 : sum[e]) + L[2 * e + 1];
+        if (0.0 == sum[e]) r2 = 0.0 + ES_LOGE2;
+        out[e] = r1 - r2;
+    }
+}
+#endif /* __cplusplus */
+
 ES_HD double es_polar_f(double a, double b, const uint64_t* tab)
 {
-    return es_logaddexp(a, b, tab) - es_logaddexp(0.0, a + b, tab);
+    double s0, s1;
+    return es_polar_f_sp(a, b, tab, &s0, &s1);
 }
 
 /* rtwm/fastpolar.py:26-29  _g_function:  b + (1 - 2u) * a  */

@@ -28,6 +28,9 @@
 // Build with -ffp-contract=off: every rounding step in es_math.h is explicit.
 #include "es_internal.h"
 #include "es_math.h"
+#ifdef ES_SCL_STAMPS
+#include <cstdio>
+#endif
 
 namespace {
 
@@ -63,7 +66,15 @@ struct SclWave {
 
 template <int L> struct SclCfg { static constexpr int WPB = (L <= 8) ? 4 : (L == 16 ? 2 : 1); };
 
+#ifdef ES_SCL_STAMPS
+#define ES_STAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); (acc) += _t - t_last; t_last = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ES_STAMP(acc) do { } while (0)
+#endif
+
 struct SclArgs {
+    unsigned long long* dbg;
     const void* llr; int is_f64; long long B;
     es_frozen_mask frozen;
     const uint16_t* data_pos;
@@ -80,6 +91,15 @@ __device__ __forceinline__ uint64_t ptr_set(uint64_t p, int depth, int slot)
     return (p & ~(63ULL << sh)) | ((uint64_t)slot << sh);
 }
 __device__ __forceinline__ int ptr_get(uint64_t p, int depth) { return (int)((p >> (6 * (depth - 1))) & 63ULL); }
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    uint64_t u; __builtin_memcpy(&u, &v, 8);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src_lane);
+    u = ((uint64_t)hi << 32) | lo;
+    double r; __builtin_memcpy(&r, &u, 8); return r;
+}
 
 __device__ __forceinline__ uint8_t crc8_bytes(const uint8_t* b, int n)
 {
@@ -169,45 +189,75 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         if (lane < 32) { for (int s = 0; s < L; ++s) W.betaL[s][lane] = 0; }
         wave_fence_lds();
 
+#ifdef ES_SCL_STAMPS
+        unsigned long long t_big = 0, t_small = 0, t_dec_f = 0, t_dec_i = 0, t_beta = 0, t_misc = 0;
+        unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
         for (int i = 0; i < N; ++i) {
             // --- LLR chain: recompute the depths that changed since leaf i-1 (fastpolar.py:127-154)
             const int top = (i == 0) ? 1 : NLEV - __builtin_ctz((unsigned)i);
+            const int sp_slot = ptr_get(ptrA, NLEV);      // slot that holds the even sibling's softplus pair
             for (int d = top; d <= NLEV; ++d) {
                 const int S = N >> d;
                 const bool is_g = (i >> (NLEV - d)) & 1;
                 const int ps = (d > 1) ? ptr_get(ptrA, d - 1) : 0;
                 const int bs = ptr_get(ptrB, d);
-                for (int j = q; j < S; j += P) {
-                    double pa, pb;
+                // parent block (depth d-1, 2S values) and destination block (depth d, S values)
+                const double* par_g = scr + ps * GSLOT + (N - 4 * S);          // depth d-1 in scratch: 0,512,768
+                const double* par_l = &W.alphaS[ps][2 * S];
+                double* dst_g = scr + path * GSLOT + (N - 2 * S);
+                double* dst_l = &W.alphaS[path][S];
+                auto load_pair = [&](int j, double& pa, double& pb) {
                     if (d == 1) {
                         if (a.is_f64) { pa = llr64[j]; pb = llr64[j + S]; }
                         else { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }
-                    } else if (d - 1 <= GDEPTH) {
-                        const double* par = scr + ps * GSLOT + (N - 4 * S);   // depth d-1 offset: 0,512,768
-                        pa = par[j]; pb = par[j + S];
-                    } else {
-                        const double* par = &W.alphaS[ps][2 * S];
-                        pa = par[j]; pb = par[j + S];
-                    }
-                    double out;
-                    if (is_g) {
+                    } else if (d - 1 <= GDEPTH) { pa = par_g[j]; pb = par_g[j + S]; }
+                    else { pa = par_l[j]; pb = par_l[j + S]; }
+                };
+                auto store_out = [&](int j, double v) { if (d <= GDEPTH) dst_g[j] = v; else dst_l[j] = v; };
+                if (is_g) {
+                    for (int j = q; j < S; j += P) {
+                        double pa, pb; load_pair(j, pa, pb);
                         const uint32_t wbits = W.betaL[bs][(S + j) >> 5];
-                        out = es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u);
-                    } else {
-                        out = es_polar_f(pa, pb, tab);
+                        store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
                     }
-                    if (d <= GDEPTH) scr[path * GSLOT + (N - 2 * S) + j] = out;  // depth d offset
-                    else W.alphaS[path][S + j] = out;
+                } else if (d == NLEV) {
+                    // even leaf: f also yields log1p(exp(-|b-a|)) and log1p(exp(-|b+a|)), i.e. the
+                    // penalty term of the odd sibling g = b -/+ a; keep them next to the slot's LLRs
+                    if (q == 0) {
+                        double pa, pb, sp_diff, sp_sum; load_pair(0, pa, pb);
+                        dst_l[0] = es_polar_f_sp(pa, pb, tab, &sp_diff, &sp_sum);
+                        W.alphaS[path][128] = sp_diff;
+                        W.alphaS[path][129] = sp_sum;
+                    }
+                } else {
+                    int j = q;
+                    for (; j + P < S; j += 2 * P) {            // two independent f chains in flight
+                        double a0, b0, a1, b1; load_pair(j, a0, b0); load_pair(j + P, a1, b1);
+                        const double o0 = es_polar_f(a0, b0, tab);
+                        const double o1 = es_polar_f(a1, b1, tab);
+                        store_out(j, o0); store_out(j + P, o1);
+                    }
+                    if (j < S) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
                 }
                 if (d <= GDEPTH) wave_fence_global(); else wave_fence_lds();
                 ptrA = ptr_set(ptrA, d, path);
+#ifdef ES_SCL_STAMPS
+                if (S >= 16) ES_STAMP(t_big); else ES_STAMP(t_small);
+#endif
             }
             const double lam = W.alphaS[path][1];
 
             // --- decision
             const bool frozen = (a.frozen.w[i >> 5] >> (i & 31)) & 1u;
             const double al = __builtin_fabs(lam);
-            const double lp = es_log1p(es_exp(-al, tab));
+            double lp;
+            if (i & 1) {
+                const uint32_t ub = (W.betaL[ptr_get(ptrB, NLEV)][0] >> 1) & 1u;   // decision of the even sibling
+                lp = W.alphaS[sp_slot][ub ? 128 : 129];
+            } else {
+                lp = es_softplus_neg(-al, tab);
+            }
             const uint32_t pref = (lam >= 0.0) ? 1u : 0u;
             uint32_t bit = 0;
             if (frozen) {                                             // fastpolar.py:281-286
@@ -218,6 +268,8 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 double pen = lp;
                 if ((uint32_t)q != pref) pen = lp + al;
                 const double m = metric + pen;
+                // stable rank of candidate c = 2*path + q among the 2*cnt live candidates
+                // (metrics staged in LDS; broadcast reads).  A v_readlane variant was measured slower.
                 const bool is_cand = (q < 2) && (path < cnt);
                 const int c = 2 * path + q;
                 if (is_cand) W.candm[c] = m;
@@ -244,6 +296,9 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 wave_fence_lds();
             }
 
+#ifdef ES_SCL_STAMPS
+            if (frozen) ES_STAMP(t_dec_f); else ES_STAMP(t_dec_i);
+#endif
             // --- partial sums: fold upward while the node is a right child (fastpolar.py:156-183)
             const int t = __builtin_ctz(~(unsigned)i);                // trailing ones of i
             if (t < NLEV) {
@@ -286,8 +341,12 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 ptrB = ptr_set(ptrB, NLEV - t, path);
                 wave_fence_lds();
             }
+            ES_STAMP(t_beta);
         }
 
+#ifdef ES_SCL_STAMPS
+        ES_STAMP(t_misc);
+#endif
         // ---------------- final ordering (fastpolar.py:335), trace-back, CRC
         if (q == 0) W.candm[path] = metric;
         wave_fence_lds();
@@ -316,6 +375,13 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         }
         if (lane == 0) a.ncand[f] = cnt;
         wave_fence_lds();
+#ifdef ES_SCL_STAMPS
+        ES_STAMP(t_misc);
+        if (lane == 0 && a.dbg && f < 64) {
+            unsigned long long* o = a.dbg + f * 8;
+            o[0] = t_big; o[1] = t_small; o[2] = t_dec_f; o[3] = t_dec_i; o[4] = t_beta; o[5] = t_misc;
+        }
+#endif
     }
 }
 
@@ -385,8 +451,26 @@ int launch_scl(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     }
     SclArgs a = a0;
     a.scratch = ctx->d_scl_scratch;
+#ifdef ES_SCL_STAMPS
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { ES_HIP_CHECK(ctx, hipMalloc(&dbg, 64 * 8 * 8)); }
+    ES_HIP_CHECK(ctx, hipMemset(dbg, 0, 64 * 8 * 8));
+    a.dbg = dbg;
+#endif
     hipLaunchKernelGGL(es_scl_kernel<L>, dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
+#ifdef ES_SCL_STAMPS
+    {   // diagnostic build only: print the per-segment cycle shares of the first frames
+        unsigned long long h[64 * 8];
+        ES_HIP_CHECK(ctx, hipDeviceSynchronize());
+        ES_HIP_CHECK(ctx, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+        const char* nm[6] = {"chain S>=16", "chain S<=8", "decide frozen", "decide info", "beta fold", "misc"};
+        unsigned long long tot = 0; for (int k = 0; k < 6; ++k) tot += h[k];
+        fprintf(stderr, "[scl stamps L=%d] frame0 total %llu cycles:", L, tot);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %s=%llu (%.1f%%)", nm[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
+        fprintf(stderr, "\n");
+    }
+#endif
     return ES_OK;
 }
 
@@ -410,6 +494,7 @@ int es_launch_scl(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int
                   uint8_t* cand_ok, int32_t* ncand, hipStream_t st)
 {
     SclArgs a{};
+    a.dbg = nullptr;
     a.llr = llr; a.is_f64 = (dtype == ES_DTYPE_F64); a.B = B;
     a.frozen = ctx->frozen; a.data_pos = ctx->d_data_pos; a.exp_tab = ctx->d_exp_tab;
     a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
