@@ -169,11 +169,26 @@ class RxEngine:
     # ------------------------------------------------------------------ metric unit
     def decode_batch(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *,
                      start: torch.Tensor | None = None, list_size: int = 8, keep_corr: bool = False):
-        """sync + LLR(variant 0 at `start`, default 0) + SCL-L for every record."""
-        sy = self.sync(frames, band, keep_corr=keep_corr)
-        llr = self.llr(sy.y, band, pn_rows, start=start, variant=0)
+        """sync + LLR(variant 0 at `start`, default 0) + SCL-L for every record.
+
+        After band-pass + correlation the chain forks: peak picking only needs `corr`, the
+        demodulator (frame start known) only `y`, so pick runs on a side HIP stream
+        while LLR + SCL run on the caller's stream (SCL leaves most of each CU's issue slots and
+        LDS free at small batch).  Both branches are joined before returning."""
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        y = self.bpf(frames, band)
+        corr = self.xcorr(y, band)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            thr, peaks, npeaks = self.pick(corr)
+        llr = self.llr(y, band, pn_rows, start=start, variant=0)
         scl = self.scl(llr, list_size=list_size, skip_if_hard_ok=True)
-        return sy, llr, scl
+        main.wait_stream(self._side)
+        for t in (thr, peaks, npeaks):
+            t.record_stream(main)
+        return SyncResult(y, corr if keep_corr else None, thr, peaks, npeaks), llr, scl
 
 
 def select_payload(scl: SclResult, row: int = 0, validator=None):

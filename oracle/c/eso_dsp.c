@@ -70,17 +70,38 @@ void eso_lfilter_f64(const double* b_in, const double* a_in, int nb, const doubl
     }
 }
 
-/* ---- a4: corr[i] = sum_k y[i+k] tpl[k] / (sqrt(sum_k y[i+k]^2) + 1e-12) ------------------- */
+/* ---- a4: corr[i] = sum_k y[i+k] tpl[k] / (sqrt(sum_k y[i+k]^2) + 1e-12) -------------------
+ * Numerator: FMA chain over ascending tap index.
+ * Window energy: all-positive partial sums shared by chunks of XC_CHUNK consecutive lags (the
+ * reference's own order is whatever BLAS ddot does; any fixed order of 63 non-negative terms is
+ * accurate to a few ulp).  For lag i in the chunk starting at c = i - i % XC_CHUNK:
+ *     core = y2[c+18] + ... + y2[c+62]            (ascending)
+ *     head = y2[c+17] + y2[c+16] + ... + y2[i]    (descending accumulation; empty when i = c+18)
+ *     tail = y2[c+63] + ... + y2[i+62]            (ascending; empty when i = c)
+ *     E[i] = (head + core) + tail
+ * which is exactly what one GPU lane (one chunk) accumulates in registers. */
+#define XC_CHUNK 19
 void eso_ncc(const double* y, int64_t n, const double* tpl, int L, double* corr)
 {
-    for (int64_t i = 0; i + L <= n; i++) {
-        double num = 0.0, en = 0.0;
-        for (int k = 0; k < L; k++) {
-            const double v = y[i + k];
-            num = __builtin_fma(v, tpl[k], num);
-            en = en + v * v;
+    const int64_t n_lags = n - L + 1;
+    for (int64_t c = 0; c < n_lags; c += XC_CHUNK) {
+        double core = 0.0;
+        for (int j = XC_CHUNK - 1; j < L; j++) core = core + y[c + j] * y[c + j];
+        double head[XC_CHUNK], tail[XC_CHUNK];
+        head[XC_CHUNK - 1] = 0.0;
+        for (int r = XC_CHUNK - 2; r >= 0; r--) head[r] = head[r + 1] + y[c + r] * y[c + r];
+        tail[0] = 0.0;
+        for (int r = 1; r < XC_CHUNK; r++) {
+            const int64_t j = c + L - 1 + r;
+            tail[r] = (j < n) ? tail[r - 1] + y[j] * y[j] : tail[r - 1];
         }
-        corr[i] = num / (sqrt(en) + 1e-12);
+        for (int r = 0; r < XC_CHUNK && c + r < n_lags; r++) {
+            const int64_t i = c + r;
+            double num = 0.0;
+            for (int k = 0; k < L; k++) num = __builtin_fma(y[i + k], tpl[k], num);
+            const double en = (head[r] + core) + tail[r];
+            corr[i] = num / (sqrt(en) + 1e-12);
+        }
     }
 }
 
