@@ -38,6 +38,8 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "es_llr_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "es_header_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "es_scl_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "es_polar_encode_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

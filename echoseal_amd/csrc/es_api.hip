@@ -186,6 +186,20 @@ int es_llr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const int32
                          score_dev, (hipStream_t)stream);
 }
 
+int es_header_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const int32_t* start_dev,
+                    const uint8_t* band_dev, const uint8_t* hdr_pn_dev, uint8_t* ok_dev, int32_t* val_dev,
+                    float* score_dev, int32_t* best_s_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0 || T < 0) return fail(ctx, ES_EINVAL, "es_header_batch: negative size");
+    if (B == 0) return ES_OK;
+    if (!y_dev || !band_dev || !hdr_pn_dev || !ok_dev || !val_dev || !score_dev)
+        return fail(ctx, ES_EINVAL, "es_header_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_header(ctx, y_dev, B, T, start_dev, band_dev, hdr_pn_dev, ok_dev, val_dev, score_dev,
+                            best_s_dev, (hipStream_t)stream);
+}
+
 int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int list_size,
                  int skip_if_hard_ok, uint8_t* hard_info_dev, uint8_t* hard_ok_dev,
                  uint8_t* cand_info_dev, double* cand_metric_dev, uint8_t* cand_ok_dev,

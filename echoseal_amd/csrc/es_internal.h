@@ -61,4 +61,7 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
                   const uint8_t* band, const uint8_t* pn, int variant, float* llr, int32_t* best_s,
                   float* score, hipStream_t st);
 
+int es_launch_header(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t* start, const uint8_t* band,
+                     const uint8_t* hdr_pn, uint8_t* ok, int32_t* val, float* score, int32_t* best_s, hipStream_t st);
+
 #endif

@@ -267,6 +267,126 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
     }
 }
 
+// ---- header decode (WatermarkDetector._decode_header, rtwm/detector.py:452-515) -----------------
+// One wave per record.  Matched filter on prefix + 128 header chips, shift search on
+// |sum(win * hdr_pn)[guard:]| (first maximum in ascending shift order), then 16 x 8 majority.
+// Eight shifts are scored at a time: lane = slot*8 + accumulator reproduces NumPy's <=128-element
+// pairwise leaf (8 strided accumulators, ((0+1)+(2+3))+((4+5)+(6+7)), tail added sequentially).
+constexpr int HD_MAXWIN = ES_HDR_L + 2 * ES_MAX_TAPS + 8;
+
+// NumPy pairwise leaf (8 <= n <= 128) evaluated by the 8 lanes of a slot; all 8 lanes return it.
+template <typename F>
+__device__ __forceinline__ float slot_leaf_sum(int n, int j, F get)
+{
+    float r = get(j);
+    const int full = n - (n % 8);
+    for (int i = 8; i < full; i += 8) r = r + get(i + j);
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (int i = full; i < n; ++i) r = r + get(i);
+    return r;
+}
+
+__global__ __launch_bounds__(64) void es_header_kernel(const double* __restrict__ y, long long B, int T,
+        const int32_t* __restrict__ start, const uint8_t* __restrict__ band, const uint8_t* __restrict__ hdr_pn,
+        const es_band_tables* __restrict__ tabs, uint8_t* __restrict__ ok_out, int32_t* __restrict__ val_out,
+        float* __restrict__ score_out, int32_t* __restrict__ best_s_out)
+{
+    __shared__ float s_rx[ES_PRE_L + ES_HDR_L];
+    __shared__ float s_h[ES_MAX_TAPS];
+    __shared__ float s_pn[ES_HDR_L];
+    __shared__ float s_win[HD_MAXWIN];
+    __shared__ float s_d[ES_HDR_L];
+    __shared__ float s_sums[16];
+    const int lane = threadIdx.x;
+    for (long long rec = blockIdx.x; rec < B; rec += gridDim.x) {
+        const int st0 = start ? start[rec] : 0;
+        const int flen = T - st0;
+        if (st0 < 0 || flen < ES_PRE_L + ES_HDR_L) {                   // :461-462
+            if (lane == 0) { ok_out[rec] = 0; val_out[rec] = 0; score_out[rec] = 0.0f; if (best_s_out) best_s_out[rec] = 0; }
+            continue;
+        }
+        const int bi = band[rec];
+        const int ntaps = tabs->ntaps[bi];
+        const int mem = ntaps - 1;
+        const int prefix = mem < ES_PRE_L ? mem : ES_PRE_L;            // :466
+        const int nfull = prefix + ES_HDR_L;
+        const double* fr = y + rec * T + st0;
+        for (int i = lane; i < nfull; i += 64) s_rx[i] = (float)fr[ES_PRE_L - prefix + i];
+        for (int i = lane; i < ntaps; i += 64) s_h[i] = tabs->taps[bi][i];
+        const uint8_t* pnr = hdr_pn + rec * (ES_HDR_L / 8);
+        for (int i = lane; i < ES_HDR_L; i += 64)
+            s_pn[i] = 2.0f * (float)((pnr[i >> 3] >> (7 - (i & 7))) & 1u) - 1.0f;
+        __syncthreads();
+        const int nmf = nfull + ntaps - 1;
+        const int offset = mem + prefix;                               // :474
+        int max_shift = ES_HDR_L / 2 + prefix;                         // :475-478
+        if (4 * ntaps < max_shift) max_shift = 4 * ntaps;
+        if (max_shift < mem) max_shift = mem;
+        const int wstart = offset - max_shift > 0 ? offset - max_shift : 0;
+        const int wstop = nmf < offset + ES_HDR_L + max_shift ? nmf : offset + ES_HDR_L + max_shift;
+        const int nwin = wstop - wstart;
+        const int base = offset - wstart;
+        int guard = ntaps / 8 < 32 ? ntaps / 8 : 32;                   // :484
+        if (guard < 8) guard = 8;
+        for (int w = lane; w < nwin; w += 64) {                        // :473 (same MF definition as _llr)
+            const int jj = wstart + w;
+            int i0 = jj - (ntaps - 1); if (i0 < 0) i0 = 0;
+            const int i1 = jj < nfull - 1 ? jj : nfull - 1;
+            double acc = 0.0;
+            for (int i = i0; i <= i1; ++i) acc += (double)s_rx[i] * (double)s_h[jj - i];
+            s_win[w] = (float)acc;
+        }
+        __syncthreads();
+        // shift search, 8 shifts per round
+        const int slot = lane >> 3, j = lane & 7;
+        const int n = ES_HDR_L - guard;
+        float best = -1.0f; int best_s = 0;
+        for (int s0 = -max_shift; s0 <= max_shift; s0 += 8) {
+            const int s = s0 + slot;
+            const int i0 = base + s;
+            const bool valid = (s <= max_shift) && i0 >= 0 && i0 + ES_HDR_L <= nwin;
+            const float* a = s_win + (valid ? i0 : base) + guard;
+            const float* b = s_pn + guard;
+            const float sum = slot_leaf_sum(n, j, [&](int i) { return a[i] * b[i]; });
+            const float sc = valid ? __builtin_fabsf(sum) : -2.0f;
+            #pragma unroll
+            for (int q = 0; q < 8; ++q) {                              // ascending shift, strict >
+                const float v = __shfl(sc, q * 8);
+                if (v > best) { best = v; best_s = s0 + q; }
+            }
+        }
+        // despread at the chosen shift, 16 x 8 majority (:498-513)
+        const int a0 = base + best_s;
+        for (int i = lane; i < ES_HDR_L; i += 64) s_d[i] = s_win[a0 + i] * s_pn[i];
+        __syncthreads();
+        if (lane < 16) {
+            const float* d = s_d + 8 * lane;
+            s_sums[lane] = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+        }
+        __syncthreads();
+        const float sum_d = slot_leaf_sum(ES_HDR_L, j, [&](int i) { return s_d[i]; });
+        const float sum_dd = slot_leaf_sum(ES_HDR_L, j, [&](int i) { return s_d[i] * s_d[i]; });
+        const float mu = sum_d / (float)ES_HDR_L;
+        const float sum_cc = slot_leaf_sum(ES_HDR_L, j, [&](int i) { const float c = s_d[i] - mu; return c * c; });
+        const float sum_abs = slot_leaf_sum(16, j, [&](int i) { return __builtin_fabsf(s_sums[i]); });
+        if (lane == 0) {
+            unsigned val = 0; int npos = 0;
+            for (int b = 0; b < 16; ++b) { val = (val << 1) | (s_sums[b] < 0.0f ? 1u : 0u); npos += s_sums[b] > 0.0f; }
+            const float mean_abs = sum_abs / 16.0f;
+            const float rms = __builtin_sqrtf(sum_dd / (float)ES_HDR_L) + (float)1e-12;
+            const float margin = mean_abs / rms;
+            const float sd = __builtin_sqrtf(sum_cc / (float)ES_HDR_L) + (float)1e-12;
+            ok_out[rec] = (uint8_t)((npos >= 10) && (margin > 0.5f));
+            val_out[rec] = (int32_t)val;
+            score_out[rec] = mean_abs / sd;
+            if (best_s_out) best_s_out[rec] = best_s;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t* start,
@@ -278,6 +398,18 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(es_llr_kernel, dim3((unsigned)blocks), dim3(LLR_THREADS), 0, st, y, (long long)B, T,
                        start, band, pn, variant, ctx->d_tables, llr, best_s, score);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}
+
+int es_launch_header(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t* start, const uint8_t* band,
+                     const uint8_t* hdr_pn, uint8_t* ok, int32_t* val, float* score, int32_t* best_s, hipStream_t st)
+{
+    long long blocks = B;
+    const long long cap = (long long)ctx->num_cu * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(es_header_kernel, dim3((unsigned)blocks), dim3(64), 0, st, y, (long long)B, T, start, band,
+                       hdr_pn, ctx->d_tables, ok, val, score, best_s);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }

@@ -52,6 +52,7 @@ class WatermarkDetector:
         if self._hdr_pn_sy.size != HDR_L:
             raise RuntimeError(f"Header PN length {self._hdr_pn_sy.size} != expected {HDR_L}")
         self._engine = engine
+        self._trace: list[tuple[int, int, int]] | None = None   # set to [] to record (band_lo, peak, ctr) tries
 
     # ------------------------------------------------------------------ engine plumbing
     @property
@@ -146,6 +147,8 @@ class WatermarkDetector:
             budget = MAX_TRIES - tried
             results = self._decode_candidates(frame, cands[:budget])
             for ctr, blobs in zip(cands, results):
+                if self._trace is not None:
+                    self._trace.append((int(band[0]), int(start), int(ctr)))
                 if self._accept(blobs, ctr):
                     return True
                 tried += 1

@@ -135,6 +135,20 @@ class RxEngine:
                                                     self._stream()), "es_llr_batch")
         return (out, best_s, score) if want_diag else out
 
+    def header(self, y: torch.Tensor, band: torch.Tensor, hdr_pn: torch.Tensor, *, start: torch.Tensor | None = None):
+        """Batched _decode_header (rtwm/detector.py:452-515) -> (ok uint8[B], val int32[B], score float32[B])."""
+        B, T = y.shape
+        if hdr_pn.shape[0] == 1 and B > 1:
+            hdr_pn = hdr_pn.expand(B, 16)
+        hdr_pn = hdr_pn.contiguous()
+        ok = torch.empty(B, dtype=torch.uint8, device=self.device)
+        val = torch.empty(B, dtype=torch.int32, device=self.device)
+        score = torch.empty(B, dtype=torch.float32, device=self.device)
+        nat.check(self._ctx, self._lib.es_header_batch(self._ctx, _ptr(y), B, T, _ptr(start), _ptr(band), _ptr(hdr_pn),
+                                                       _ptr(ok), _ptr(val), _ptr(score), None, self._stream()),
+                  "es_header_batch")
+        return ok, val, score
+
     # ------------------------------------------------------------------ FEC
     def scl(self, llr: torch.Tensor, *, list_size: int = 8, skip_if_hard_ok: bool = True) -> SclResult:
         if llr.dim() != 2 or llr.shape[1] != 1024:

@@ -104,6 +104,16 @@ int es_llr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const int32
                  const uint8_t* band_dev, const uint8_t* pn_dev, int variant, float* llr_dev,
                  int32_t* best_s_dev, float* score_dev, void* stream);
 
+/* Header decode (16-bit counter, each bit repeated 8x, spread with the static header PN):
+ *   replaces WatermarkDetector._decode_header (rtwm/detector.py:452-515)
+ *   y_dev      [B][T] float64 band-passed records, start_dev [B] frame start (nullable = 0)
+ *   hdr_pn_dev [B][16] packed header PN bits (pn_bits(0, 128), MSB first)
+ *   ok_dev [B] uint8, val_dev [B] int32 (ctr & 0xFFFF estimate), score_dev [B] float32,
+ *   best_s_dev [B] int32 (nullable)                                                          */
+int es_header_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const int32_t* start_dev,
+                    const uint8_t* band_dev, const uint8_t* hdr_pn_dev, uint8_t* ok_dev, int32_t* val_dev,
+                    float* score_dev, int32_t* best_s_dev, void* stream);
+
 /* Polar(1024,448)+CRC-8 decode: hard-decision shortcut and successive-cancellation list.
  *   replaces PolarCode.decode (rtwm/fastpolar.py:254-359) up to validator selection
  *   llr_dev         [B][1024] ES_DTYPE_F32 or ES_DTYPE_F64

@@ -309,3 +309,75 @@ void eso_llr(const double* frame, int flen, const uint8_t* pn_bits, const float*
     if (diag) { diag[0] = best_s; diag[1] = best; diag[2] = second; diag[3] = n; }
     free(pn); free(d); free(mf); free(rx);
 }
+
+/* ---- header decode: WatermarkDetector._decode_header (rtwm/detector.py:452-515) ---------------
+ * frame   : band-passed samples (float64), flen >= 191 of them used
+ * hdr_pn  : 128 PN bits {0,1} of counter 0 (static header PN)
+ * h,ntaps : matched-filter taps
+ * out[3]  : ok (0/1), 16-bit value, score.   diag (nullable): best_s, |corr| of the best shift.
+ * NumPy float32 semantics throughout (pairwise sums; the (16,8) row sums are 8-element pairwise
+ * leaves; python-float constants are weak and cast to float32). */
+void eso_decode_header(const double* frame, int flen, const uint8_t* hdr_pn, const float* h, int ntaps,
+                       double* out, double* diag)
+{
+    out[0] = 0; out[1] = 0; out[2] = 0.0;
+    if (diag) { diag[0] = 0; diag[1] = -1; }
+    if (flen < PRE_L + HDR_L) return;                                   /* :461-462 */
+    const int mem = ntaps - 1;
+    const int prefix = mem < PRE_L ? mem : PRE_L;                       /* :466 */
+    const int nfull = prefix + HDR_L;
+    float rx[PRE_L + HDR_L];
+    for (int i = 0; i < nfull; i++) rx[i] = (float)frame[PRE_L - prefix + i];
+    const int nmf = nfull + ntaps - 1;
+    float* mf = (float*)malloc(sizeof(float) * (size_t)nmf);
+    for (int j = 0; j < nmf; j++) {                                     /* :473, same MF definition as _llr */
+        int i0 = j - (ntaps - 1); if (i0 < 0) i0 = 0;
+        int i1 = j < nfull - 1 ? j : nfull - 1;
+        double acc = 0.0;
+        for (int i = i0; i <= i1; i++) acc += (double)rx[i] * (double)h[j - i];
+        mf[j] = (float)acc;
+    }
+    const int offset = mem + prefix;                                    /* :474 */
+    int max_shift = HDR_L / 2 + prefix;                                 /* :475-478 */
+    if (4 * ntaps < max_shift) max_shift = 4 * ntaps;
+    if (max_shift < mem) max_shift = mem;
+    const int start = offset - max_shift > 0 ? offset - max_shift : 0;
+    const int stop = nmf < offset + HDR_L + max_shift ? nmf : offset + HDR_L + max_shift;
+    const float* win = mf + start;
+    const int nwin = stop - start;
+    const int base = offset - start;
+    int guard = ntaps / 8 < 32 ? ntaps / 8 : 32;                        /* :484 */
+    if (guard < 8) guard = 8;
+    float pn[HDR_L], d[HDR_L];
+    for (int i = 0; i < HDR_L; i++) pn[i] = 2.0f * (float)hdr_pn[i] - 1.0f;
+    int best_s = 0; double best = -1.0;
+    for (int s = -max_shift; s <= max_shift; s++) {                     /* :487-497 */
+        const int i0 = base + s;
+        if (i0 < 0 || i0 + HDR_L > nwin) continue;
+        for (int i = guard; i < HDR_L; i++) d[i] = win[i0 + i] * pn[i];
+        const double score = fabs((double)pairwise_f32(d + guard, HDR_L - guard));
+        if (score > best) { best = score; best_s = s; }
+    }
+    const int i0 = base + best_s;
+    for (int i = 0; i < HDR_L; i++) d[i] = win[i0 + i] * pn[i];          /* :498-500 */
+    float sums[16], asum[16], dd[HDR_L];
+    int npos = 0; unsigned val = 0;
+    for (int b = 0; b < 16; b++) {                                      /* :503-509 */
+        sums[b] = pairwise_f32(d + 8 * b, 8);
+        asum[b] = fabsf(sums[b]);
+        val = (val << 1) | (sums[b] < 0.0f ? 1u : 0u);
+        npos += sums[b] > 0.0f;
+    }
+    for (int i = 0; i < HDR_L; i++) dd[i] = d[i] * d[i];
+    const float mean_abs = pairwise_f32(asum, 16) / 16.0f;
+    const float rms = sqrtf(pairwise_f32(dd, HDR_L) / (float)HDR_L) + (float)1e-12;   /* :505 */
+    const float margin = mean_abs / rms;
+    const float mu = pairwise_f32(d, HDR_L) / (float)HDR_L;              /* np.std(d), :512 */
+    for (int i = 0; i < HDR_L; i++) { const float c = d[i] - mu; dd[i] = c * c; }
+    const float sd = sqrtf(pairwise_f32(dd, HDR_L) / (float)HDR_L) + (float)1e-12;
+    out[0] = (npos >= 10) && (margin > 0.5f);                           /* :513 */
+    out[1] = (double)val;
+    out[2] = (double)(mean_abs / sd);
+    if (diag) { diag[0] = best_s; diag[1] = best; }
+    free(mf);
+}

@@ -129,3 +129,11 @@ def decode_frame(frame_f32, ba, tpl, taps, pn_full_bits, L=8, start=0):
     info, ok, took = polar_decode(l.astype(np.float64), L)
     return dict(y=y, corr=corr, thr=thr, peaks=peaks, npeaks=tot, fallback=fb, llr=l, best_s=best_s,
                 info=np.packbits(info).tobytes(), ok=ok, took_list=took)
+
+
+def decode_header(frame, hdr_pn_bits, taps):
+    """WatermarkDetector._decode_header -> (ok, value, score, best_s)."""
+    frame = _c(frame, np.float64); pn = _c(hdr_pn_bits, np.uint8); h = _c(taps, np.float32)
+    out = np.zeros(3); diag = np.zeros(2)
+    lib().eso_decode_header(_p(frame), int(frame.size), _p(pn), _p(h), int(h.size), _p(out), _p(diag))
+    return bool(out[0]), int(out[1]), float(out[2]), int(diag[0])
