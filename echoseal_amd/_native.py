@@ -19,7 +19,7 @@ ES_PRE_L = 63
 ES_NBANDS = 4
 ES_MAX_TAPS = 160
 ES_MAX_PEAKS = 32
-ES_MAX_LIST = 32
+ES_MAX_LIST = 256
 ES_PN_BYTES = 152
 ES_INFO_BYTES = 55
 ES_DTYPE_F32, ES_DTYPE_I16, ES_DTYPE_F64 = 0, 1, 2

@@ -30,7 +30,7 @@ es_ctx* es_create(int device, int list_size_max)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device visible"; return nullptr; }
     if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return nullptr; }
-    if (list_size_max < 1 || list_size_max > ES_MAX_LIST) { g_create_err = "list_size_max must be in [1, 32]"; return nullptr; }
+    if (list_size_max < 1 || list_size_max > ES_MAX_LIST) { g_create_err = "list_size_max must be in [1, 256]"; return nullptr; }
     es_ctx* ctx = new (std::nothrow) es_ctx();
     if (!ctx) { g_create_err = "out of host memory"; return nullptr; }
     ctx->device = device;
@@ -56,6 +56,13 @@ es_ctx* es_create(int device, int list_size_max)
         es_destroy(ctx);
         return nullptr;
     }
+    ctx->wide_scratch_bytes = es_scl_wide_scratch_bytes(ctx, &ctx->wide_slots);
+    if (ctx->wide_scratch_bytes && hipMalloc(&ctx->d_wide_scratch, ctx->wide_scratch_bytes) != hipSuccess) {
+        g_create_err = "device allocation of the wide-list SCL scratch slab failed";
+        ctx->d_wide_scratch = nullptr;
+        es_destroy(ctx);
+        return nullptr;
+    }
     return ctx;
 }
 
@@ -68,6 +75,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_exp_tab) (void)hipFree(ctx->d_exp_tab);
     if (ctx->d_scl_scratch) (void)hipFree(ctx->d_scl_scratch);
     if (ctx->d_ws_corr) (void)hipFree(ctx->d_ws_corr);
+    if (ctx->d_wide_scratch) (void)hipFree(ctx->d_wide_scratch);
     delete ctx;
 }
 
@@ -214,6 +222,9 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     if (!llr_dev || !hard_info_dev || !hard_ok_dev || !cand_info_dev || !cand_metric_dev || !cand_ok_dev || !ncand_dev)
         return fail(ctx, ES_EINVAL, "es_scl_batch: null pointer");
     DeviceGuard g(ctx->device);
+    if (list_size > 32)
+        return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
+                                  cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     return es_launch_scl(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                          cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
 }

@@ -479,7 +479,7 @@ int launch_scl(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
 size_t es_scl_scratch_bytes(const es_ctx* ctx)
 {
     size_t need = 0, n;
-    const int lmax = ctx->list_size_max;
+    const int lmax = ctx->list_size_max;   /* lists above 32 use es_scl_wide.hip */
     if (lmax >= 1  && (n = scl_scratch_need<1>(ctx))  > need) need = n;
     if (lmax >= 2  && (n = scl_scratch_need<2>(ctx))  > need) need = n;
     if (lmax >= 4  && (n = scl_scratch_need<4>(ctx))  > need) need = n;

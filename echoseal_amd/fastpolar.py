@@ -25,7 +25,8 @@ def default_engine():
     if _engine is None:
         import torch
         from .engine import RxEngine
-        _engine = RxEngine(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        # 256 = the detector's default list size (rtwm/detector.py:27); costs ~1.1 GB of scratch
+        _engine = RxEngine(torch.cuda.current_device() if torch.cuda.is_available() else 0, list_size_max=256)
     return _engine
 
 

@@ -39,7 +39,7 @@ extern "C" {
 #define ES_NBANDS         4
 #define ES_MAX_TAPS     160   /* reference taps are 93..131 long (rtwm/detector.py:260-294) */
 #define ES_MAX_PEAKS     32   /* detector consumes at most 25 peaks per scan (rtwm/detector.py:108) */
-#define ES_MAX_LIST      32
+#define ES_MAX_LIST     256   /* 1..32: one wavefront per frame; 64..256: one workgroup per frame */
 #define ES_PN_BYTES     152   /* ceil(1215 / 8): packed PN row of one frame counter */
 
 #define ES_DTYPE_F32      0
@@ -117,7 +117,7 @@ int es_header_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const in
 /* Polar(1024,448)+CRC-8 decode: hard-decision shortcut and successive-cancellation list.
  *   replaces PolarCode.decode (rtwm/fastpolar.py:254-359) up to validator selection
  *   llr_dev         [B][1024] ES_DTYPE_F32 or ES_DTYPE_F64
- *   list_size       1, 2, 4, 8, 16 or 32
+ *   list_size       a power of two, 1..256 (<= the context's list_size_max)
  *   skip_if_hard_ok non-zero: records whose hard decision passes CRC skip the list loop
  *                   (the reference's behaviour when validator is None, fastpolar.py:268-276)
  *   hard_info_dev   [B][55], hard_ok_dev [B]

@@ -263,3 +263,46 @@ def test_polarcode_api_on_gpu(golden_polar):
         decode(np.zeros(1000))
     with pytest.raises(ValueError):
         encode(b"short")
+
+
+@pytest.mark.parametrize("L", [64, 128, 256])
+def test_scl_wide_lists_vs_oracle(oracle, L):
+    """Lists above 32 (the detector's default is 256) run on the workgroup-per-frame kernel."""
+    from echoseal_amd.engine import RxEngine
+    eng = RxEngine(0, list_size_max=256)
+    rng = np.random.default_rng(500 + L)
+    llr = np.clip(rng.normal(0, 3, (6, 1024)), -12, 12)
+    llr[0] = 0.0; llr[0, 0] = 1e-3
+    llr[1] = np.where(rng.integers(0, 2, 1024) == 1, 12.0, -12.0)
+    for dt in (np.float32, np.float64):
+        x = llr.astype(dt)
+        res = eng.scl(torch.from_numpy(x).to(eng.device), list_size=L, skip_if_hard_ok=False)
+        for i in range(x.shape[0]):
+            nn, ci, cm, cc = oracle.scl_list(x[i].astype(np.float64), L)
+            assert int(res.ncand[i]) == nn == L
+            assert np.array_equal(cm, res.cand_metric[i].cpu().numpy()), (L, i)
+            assert np.array_equal(np.packbits(ci, axis=1), res.cand_info[i].cpu().numpy()), (L, i)
+            assert np.array_equal(cc, res.cand_ok[i].cpu().numpy()), (L, i)
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["default", "glibc"])
+def test_scl_wide_matches_reference_golden(mode):
+    import os
+    from echoseal_amd.engine import RxEngine, select_payload
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"polar_wide_{mode}.npz"))
+    eng = RxEngine(0, list_size_max=256)
+    names = sorted({k.split("/")[0] for k in g.files if k.endswith("/llr")})
+    for L in (64, 256):
+        for n in names:
+            llr = g[f"{n}/llr"]
+            x = torch.from_numpy(np.ascontiguousarray(llr)).to(eng.device).reshape(1, 1024)
+            res = eng.scl(x, list_size=L, skip_if_hard_ok=True)
+            payload, ok = select_payload(res, 0, None)
+            assert ok == bool(g[f"{n}/L{L}/ok"]) and payload == g[f"{n}/L{L}/info"].tobytes(), (n, L)
+            key = f"{n}/L{L}/cand_metric"
+            if key in g.files:
+                assert np.array_equal(res.cand_info[0].cpu().numpy(), g[f"{n}/L{L}/cand_info"])
+                m = res.cand_metric[0].cpu().numpy()
+                assert np.array_equal(m, g[key]) if mode == "glibc" else np.allclose(m, g[key], rtol=1e-13, atol=0)
+    eng.close()

@@ -91,3 +91,19 @@ def test_all_candidates_tie(oracle, L):
     assert n == L and np.all(np.diff(cm) >= 0)
     n2, ci2, cm2, _ = oracle.scl_list(llr, L)
     assert np.array_equal(ci, ci2) and np.array_equal(cm, cm2)
+
+
+@pytest.mark.parametrize("mode", ["default", "glibc"])
+def test_wide_lists_match_reference(oracle, mode):
+    """L = 64 and 256 (detector default) against tests/golden/polar_wide_*.npz."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"polar_wide_{mode}.npz"))
+    for name in sorted({k.split("/")[0] for k in g.files if k.endswith("/llr")}):
+        for L in (64, 256):
+            info, ok, took = oracle.polar_decode(g[f"{name}/llr"], L)
+            assert ok == bool(g[f"{name}/L{L}/ok"]) and np.array_equal(np.packbits(info), g[f"{name}/L{L}/info"])
+            key = f"{name}/L{L}/cand_metric"
+            if key in g.files:
+                n, ci, cm, cc = oracle.scl_list(g[f"{name}/llr"], L)
+                assert np.array_equal(np.packbits(ci, axis=1), g[f"{name}/L{L}/cand_info"])
+                assert np.array_equal(cm, g[key]) if mode == "glibc" else np.allclose(cm, g[key], rtol=1e-13, atol=0)
