@@ -178,6 +178,16 @@ def main() -> None:
 
     if rank == 0:
         achieved = XCORR_BYTES_PER_FRAME * B / (xcorr_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
+        # the gfx950 guide prescribes, WRITE_SIZE as read); measured on the 1024-record launch.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_xcorr_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)["es_xcorr_kernel"]["B=1024 (C2 launch)"]
+            if B == 1024:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "watermark frames/sec decoded (sync+LLR+SCL-8) @ 48 kHz",
             "value": total * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
@@ -189,7 +199,7 @@ def main() -> None:
                        "sharding": f"{world} x {B} frames, schedule broadcast from rank 0",
                        "sync_offsets_ok": ok_sync, "frames_through_list_decoder": listed},
             "roofline": {"kernel": "es_xcorr_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": xcorr_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_FRAME * B},
             "roofline_c3": {"kernel": "es_xcorr_kernel", "bound": "hbm", "achieved": big, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": big / HBM_PEAK_GBS, "launch_ms": big_ms,
