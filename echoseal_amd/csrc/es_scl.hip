@@ -117,6 +117,8 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
 {
     constexpr int WPB = SclCfg<L>::WPB;
     constexpr int P = 64 / L;
+    constexpr int LGP = (P == 64) ? 6 : (P == 32) ? 5 : (P == 16) ? 4 : (P == 8) ? 3 : (P == 4) ? 2 : 1;
+    constexpr int RD = NLEV - LGP;      // depths RD..10 (block sizes P..1) live in registers
     __shared__ __attribute__((aligned(16))) uint64_t s_exp[ES_EXP_TAB_WORDS];
     __shared__ uint16_t s_dpos[KINFO];
     __shared__ SclWave<L> s_wave[WPB];
@@ -184,6 +186,12 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         // ---------------- list decoding (fastpolar.py:278-330)
         uint64_t ptrA = 0, ptrB = 0;      // every path starts as a mirror of path 0
         double metric = 0.0;
+        // Bottom of the LLR tree in registers: ar[k] is element (q mod (P>>k)) of this path's open
+        // node at depth RD+k, replicated over the path's P lanes.  sp_* = softplus pair of the even leaf.
+        double ar[LGP + 1];
+        #pragma unroll
+        for (int k = 0; k <= LGP; ++k) ar[k] = 0.0;
+        double sp_diff = 0.0, sp_sum = 0.0;
         int cnt = 1;                      // live paths
         int info_idx = 0;
         if (lane < 32) { for (int s = 0; s < L; ++s) W.betaL[s][lane] = 0; }
@@ -196,8 +204,8 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         for (int i = 0; i < N; ++i) {
             // --- LLR chain: recompute the depths that changed since leaf i-1 (fastpolar.py:127-154)
             const int top = (i == 0) ? 1 : NLEV - __builtin_ctz((unsigned)i);
-            const int sp_slot = ptr_get(ptrA, NLEV);      // slot that holds the even sibling's softplus pair
-            for (int d = top; d <= NLEV; ++d) {
+            // (a) depths above the register-resident part: slot storage in scratch / LDS
+            for (int d = top; d < RD; ++d) {
                 const int S = N >> d;
                 const bool is_g = (i >> (NLEV - d)) & 1;
                 const int ps = (d > 1) ? ptr_get(ptrA, d - 1) : 0;
@@ -221,15 +229,6 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                         const uint32_t wbits = W.betaL[bs][(S + j) >> 5];
                         store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
                     }
-                } else if (d == NLEV) {
-                    // even leaf: f also yields log1p(exp(-|b-a|)) and log1p(exp(-|b+a|)), i.e. the
-                    // penalty term of the odd sibling g = b -/+ a; keep them next to the slot's LLRs
-                    if (q == 0) {
-                        double pa, pb, sp_diff, sp_sum; load_pair(0, pa, pb);
-                        dst_l[0] = es_polar_f_sp(pa, pb, tab, &sp_diff, &sp_sum);
-                        W.alphaS[path][128] = sp_diff;
-                        W.alphaS[path][129] = sp_sum;
-                    }
                 } else {
                     int j = q;
                     for (; j + P < S; j += 2 * P) {            // two independent f chains in flight
@@ -243,10 +242,72 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 if (d <= GDEPTH) wave_fence_global(); else wave_fence_lds();
                 ptrA = ptr_set(ptrA, d, path);
 #ifdef ES_SCL_STAMPS
-                if (S >= 16) ES_STAMP(t_big); else ES_STAMP(t_small);
+                ES_STAMP(t_big);
 #endif
             }
-            const double lam = W.alphaS[path][1];
+            // (b) depth RD: one element per lane, straight from the slot of depth RD-1 into a register
+            if (RD >= top) {
+                const int d = RD;
+                const bool is_g = (i >> (NLEV - d)) & 1;
+                double pa, pb;
+                if (d == 1) {
+                    if (a.is_f64) { pa = llr64[q]; pb = llr64[q + P]; }
+                    else { pa = (double)llr32[q]; pb = (double)llr32[q + P]; }
+                } else if (d - 1 <= GDEPTH) {
+                    const double* par = scr + ptr_get(ptrA, d - 1) * GSLOT + (N - 4 * P);
+                    pa = par[q]; pb = par[q + P];
+                } else {
+                    const double* par = &W.alphaS[ptr_get(ptrA, d - 1)][2 * P];
+                    pa = par[q]; pb = par[q + P];
+                }
+                if (is_g) {
+                    const uint32_t wbits = W.betaL[ptr_get(ptrB, d)][(P + q) >> 5];
+                    ar[0] = es_polar_g(pa, pb, (wbits >> ((P + q) & 31)) & 1u);
+                } else {
+                    ar[0] = es_polar_f(pa, pb, tab);
+                }
+            }
+            // (c) depths RD+1..10: register to register.  The node has S = P>>k elements, so the two
+            // softplus terms of f(a,b) go to two different lanes (lane bit S selects |a-b| or |a+b|)
+            // and are exchanged with one xor-shuffle: one softplus stream instead of two.
+            #pragma unroll
+            for (int k = 1; k <= LGP; ++k) {
+                const int d = RD + k;
+                if (d >= top) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int S = P >> k;
+                    const bool is_g = (i >> (NLEV - d)) & 1;
+                    const double own = ar[k - 1];
+                    const double oth = __shfl_xor(own, S);
+                    const bool hi = (q & S) != 0;                    // this lane holds parent[j+S]
+                    const double pa = hi ? oth : own;                // parent[j]
+                    const double pb = hi ? own : oth;                // parent[j+S]
+                    if (is_g) {
+                        const int j = q & (S - 1);
+                        const uint32_t wbits = W.betaL[ptr_get(ptrB, d)][(S + j) >> 5];
+                        ar[k] = es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u);
+                    } else {
+                        const double sum = pa + pb;
+                        const double d1 = pa - pb, d2 = 0.0 - sum;
+                        const bool pos1 = d1 > 0, pos2 = d2 > 0;
+                        const double t1 = pos1 ? -d1 : d1, t2 = pos2 ? -d2 : d2;
+                        const double mine = es_softplus_neg(hi ? t2 : t1, tab);
+                        const double theirs = __shfl_xor(mine, S);
+                        const double L1 = hi ? theirs : mine;         // log1p(exp(-|a-b|))
+                        const double L2 = hi ? mine : theirs;         // log1p(exp(-|a+b|))
+                        double r1 = (pos1 ? pa : pb) + L1;
+                        if (pa == pb) r1 = pa + ES_LOGE2;
+                        double r2 = (pos2 ? 0.0 : sum) + L2;
+                        if (0.0 == sum) r2 = 0.0 + ES_LOGE2;
+                        ar[k] = r1 - r2;
+                        if (k == LGP) { sp_diff = L1; sp_sum = L2; }  // penalties of the odd sibling
+                    }
+                }
+            }
+#ifdef ES_SCL_STAMPS
+            ES_STAMP(t_small);
+#endif
+            const double lam = ar[LGP];
 
             // --- decision
             const bool frozen = (a.frozen.w[i >> 5] >> (i & 31)) & 1u;
@@ -254,7 +315,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
             double lp;
             if (i & 1) {
                 const uint32_t ub = (W.betaL[ptr_get(ptrB, NLEV)][0] >> 1) & 1u;   // decision of the even sibling
-                lp = W.alphaS[sp_slot][ub ? 128 : 129];
+                lp = ub ? sp_diff : sp_sum;
             } else {
                 lp = es_softplus_neg(-al, tab);
             }
@@ -290,6 +351,12 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 ptrA = __shfl(ptrA, parent * P);
                 ptrB = __shfl(ptrB, parent * P);
                 metric = nm;
+                // register-resident nodes follow their path; a depth whose subtree is complete after
+                // this leaf is dead and need not move
+                #pragma unroll
+                for (int k = 0; k <= LGP; ++k)
+                    if (((i + 1) & ((1 << (LGP - k)) - 1)) != 0) ar[k] = __shfl(ar[k], parent * P + q);
+                if (!(i & 1)) { sp_diff = __shfl(sp_diff, parent * P + q); sp_sum = __shfl(sp_sum, parent * P + q); }
                 if (q == 0 && path < keep) W.tb[info_idx][path] = (uint8_t)myc;
                 cnt = keep;
                 ++info_idx;
