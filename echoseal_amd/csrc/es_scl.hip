@@ -191,7 +191,10 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         double ar[LGP + 1];
         #pragma unroll
         for (int k = 0; k <= LGP; ++k) ar[k] = 0.0;
-        double sp_diff = 0.0, sp_sum = 0.0;
+        double sp_diff = 0.0, sp_sum = 0.0, lp_odd = 0.0;
+        // partial-sum blocks of depths 6..10 (sizes 16..1, block of S bits at bit S): one dword per path,
+        // carried by value and moved together with ptrB at a sort; deeper words stay in LDS (betaL).
+        uint32_t b0 = 0;
         int cnt = 1;                      // live paths
         int info_idx = 0;
         if (lane < 32) { for (int s = 0; s < L; ++s) W.betaL[s][lane] = 0; }
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 if (is_g) {
                     for (int j = q; j < S; j += P) {
                         double pa, pb; load_pair(j, pa, pb);
-                        const uint32_t wbits = W.betaL[bs][(S + j) >> 5];
+                        const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + j) >> 5];
                         store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
                     }
                 } else {
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                     pa = par[q]; pb = par[q + P];
                 }
                 if (is_g) {
-                    const uint32_t wbits = W.betaL[ptr_get(ptrB, d)][(P + q) >> 5];
+                    const uint32_t wbits = (P <= 16) ? b0 : W.betaL[ptr_get(ptrB, d)][(P + q) >> 5];
                     ar[0] = es_polar_g(pa, pb, (wbits >> ((P + q) & 31)) & 1u);
                 } else {
                     ar[0] = es_polar_f(pa, pb, tab);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                     const double pb = hi ? own : oth;                // parent[j+S]
                     if (is_g) {
                         const int j = q & (S - 1);
-                        const uint32_t wbits = W.betaL[ptr_get(ptrB, d)][(S + j) >> 5];
+                        const uint32_t wbits = (S <= 16) ? b0 : W.betaL[ptr_get(ptrB, d)][(S + j) >> 5];
                         ar[k] = es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u);
                     } else {
                         const double sum = pa + pb;
@@ -314,8 +317,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
             const double al = __builtin_fabs(lam);
             double lp;
             if (i & 1) {
-                const uint32_t ub = (W.betaL[ptr_get(ptrB, NLEV)][0] >> 1) & 1u;   // decision of the even sibling
-                lp = ub ? sp_diff : sp_sum;
+                lp = lp_odd;                                         // set when the even sibling was decided
             } else {
                 lp = es_softplus_neg(-al, tab);
             }
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 double pen = lp;
                 if (pref != 0u) pen = lp + al;
                 metric = metric + pen;
+                lp_odd = sp_sum;                                      // sibling g = b + a when this bit is 0
             } else {                                                  // fastpolar.py:288-330
                 double pen = lp;
                 if ((uint32_t)q != pref) pen = lp + al;
@@ -342,21 +345,40 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                     rank += ((mk < m) || (mk == m && k < c)) ? 1 : 0;
                 }
                 const int keep = nc < L ? nc : L;
-                if (is_cand && rank < keep) W.sel[rank] = (uint8_t)c;
-                wave_fence_lds();
-                const int myc = W.sel[path < keep ? path : 0];
-                const int parent = myc >> 1;
-                bit = (uint32_t)(myc & 1);
-                const double nm = W.candm[myc];
+                // new path r continues the candidate of rank r; `src` = lane holding that candidate
+                // (parent * P + bit).  Dead paths mirror rank 0.
+                int src;
+                if constexpr (L <= 0) {   // ballot-based inversion measured slower than the LDS scatter; kept for reference
+                    const int want = path < keep ? path : 0;
+                    src = 0;
+                    #pragma unroll
+                    for (int r = 0; r < L; ++r) {                     // inverse permutation through ballots
+                        const unsigned long long holders = __ballot(is_cand && rank == r);
+                        const int ln = (int)__builtin_ctzll(holders | (1ULL << 63));
+                        if (want == r) src = ln;
+                    }
+                } else {
+                    if (is_cand && rank < keep) W.sel[rank] = (uint8_t)c;
+                    wave_fence_lds();
+                    const int cc = W.sel[path < keep ? path : 0];
+                    src = (cc >> 1) * P + (cc & 1);
+                }
+                const int parent = src / P;
+                bit = (uint32_t)(src % P);
+                const int myc = 2 * parent + (int)bit;
+                metric = __shfl(m, src);
                 ptrA = __shfl(ptrA, parent * P);
-                ptrB = __shfl(ptrB, parent * P);
-                metric = nm;
+                ptrB = __shfl((ptrB & 0xffffffffULL) | ((uint64_t)b0 << 32), parent * P);
+                b0 = (uint32_t)(ptrB >> 32);
+                ptrB &= 0xffffffffULL;
                 // register-resident nodes follow their path; a depth whose subtree is complete after
                 // this leaf is dead and need not move
                 #pragma unroll
                 for (int k = 0; k <= LGP; ++k)
                     if (((i + 1) & ((1 << (LGP - k)) - 1)) != 0) ar[k] = __shfl(ar[k], parent * P + q);
-                if (!(i & 1)) { sp_diff = __shfl(sp_diff, parent * P + q); sp_sum = __shfl(sp_sum, parent * P + q); }
+                // penalty of the odd sibling: parent lane 0 offers log1p(exp(-|b+a|)) (bit 0), lane 1
+                // log1p(exp(-|b-a|)) (bit 1); one shuffle fetches the right one
+                if (!(i & 1)) lp_odd = __shfl((q & 1) ? sp_diff : sp_sum, src);
                 if (q == 0 && path < keep) W.tb[info_idx][path] = (uint8_t)myc;
                 cnt = keep;
                 ++info_idx;
@@ -373,20 +395,16 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 const int t5 = t < 5 ? t : 5;
                 for (int s = 0; s < t5; ++s) {
                     const int S = 1 << s;
-                    const int bs = ptr_get(ptrB, NLEV - s);
-                    const uint32_t left = (W.betaL[bs][0] >> S) & ((1u << S) - 1u);
+                    const uint32_t left = (b0 >> S) & ((1u << S) - 1u);
                     cur = (left ^ cur) | (cur << S);
                 }
                 if (t <= 5) {
-                    if (q == 0) {
-                        if (t < 5) {
-                            const int Sp = 1 << t;
-                            const uint32_t mask = ((1u << Sp) - 1u) << Sp;
-                            const uint32_t w = W.betaL[path][0];
-                            W.betaL[path][0] = (w & ~mask) | (cur << Sp);
-                        } else {
-                            W.betaL[path][1] = cur;
-                        }
+                    if (t < 5) {
+                        const int Sp = 1 << t;
+                        const uint32_t mask = ((1u << Sp) - 1u) << Sp;
+                        b0 = (b0 & ~mask) | (cur << Sp);
+                    } else if (q == 0) {
+                        W.betaL[path][1] = cur;
                     }
                 } else {
                     if (q == 0) W.curb[path][0] = cur;
@@ -405,8 +423,10 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                     const int Wp = 1 << (t - 5);
                     for (int w = q; w < Wp; w += P) W.betaL[path][Wp + w] = W.curb[path][w];
                 }
-                ptrB = ptr_set(ptrB, NLEV - t, path);
-                wave_fence_lds();
+                if (t >= 5) {                                         // blocks of 32+ bits live in LDS slots
+                    ptrB = ptr_set(ptrB, NLEV - t, path);
+                    wave_fence_lds();
+                }
             }
             ES_STAMP(t_beta);
         }
