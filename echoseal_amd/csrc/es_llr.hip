@@ -25,6 +25,8 @@ constexpr int PAYLOAD_START = ES_PRE_L + ES_HDR_L;   // 191
 constexpr int LLR_THREADS = 256;
 constexpr int MAX_RX = NPAY + ES_MAX_TAPS;           // prefix + payload
 constexpr int MAX_WIN = NPAY + 2 * ES_MAX_TAPS + 8;  // matched-filter window
+constexpr int MF_R = 6;                              // matched-filter outputs per thread
+constexpr int MF_PAD = 176;                          // >= ES_MAX_TAPS rounded up to a multiple of MF_R, + slack
 
 struct PwPlan { int start[16]; int len[16]; };
 
@@ -122,17 +124,71 @@ __device__ float wave_median_f32(const float* v, int n, int lane)
     return (lo + hi) / 2.0f;
 }
 
+// k-th smallest (0-based) 32-bit key among key(i), i in [0, n), by the whole 256-thread block:
+// four 8-bit-digit passes with an LDS histogram and a wave-scan prefix.  All threads return it.
+template <typename F>
+__device__ uint32_t block_select_key32(int n, int k, F key, uint32_t* s_hist, uint32_t* s_pref, int* s_k)
+{
+    uint32_t prefix = 0;
+    int kk = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t himask = (shift == 24) ? 0u : (~0u << (shift + 8));
+        for (int i = threadIdx.x; i < n; i += LLR_THREADS) {
+            const uint32_t kx = key(i);
+            if ((kx & himask) == prefix) atomicAdd(&s_hist[(kx >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        {
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            const uint32_t h = s_hist[threadIdx.x];
+            uint32_t incl = h;
+            #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            __syncthreads();
+            if (lane == 63) s_hist[wv] = incl;
+            __syncthreads();
+            uint32_t basec = 0;
+            for (int w = 0; w < wv; ++w) basec += s_hist[w];
+            incl += basec;
+            const uint32_t excl = incl - h;
+            if ((int)excl <= kk && kk < (int)incl) { *s_k = kk - (int)excl; *s_pref = prefix | ((uint32_t)threadIdx.x << shift); }
+        }
+        __syncthreads();
+        prefix = *s_pref;
+        kk = *s_k;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+template <typename F>
+__device__ float block_median_f32(int n, F val, uint32_t* s_hist, uint32_t* s_pref, int* s_k)
+{
+    auto key = [&](int i) { return f32_key(val(i)); };
+    if (n & 1) return key_f32(block_select_key32(n, n / 2, key, s_hist, s_pref, s_k));
+    const float lo = key_f32(block_select_key32(n, n / 2 - 1, key, s_hist, s_pref, s_k));
+    const float hi = key_f32(block_select_key32(n, n / 2, key, s_hist, s_pref, s_k));
+    return (lo + hi) / 2.0f;
+}
+
 __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __restrict__ y, long long B,
         int T, const int32_t* __restrict__ start, const uint8_t* __restrict__ band,
         const uint8_t* __restrict__ pn_rows, int variant, const es_band_tables* __restrict__ tabs,
         float* __restrict__ llr, int32_t* __restrict__ best_s_out, float* __restrict__ score_out)
 {
-    __shared__ float s_rx[MAX_RX];
-    __shared__ float s_h[ES_MAX_TAPS];
+    __shared__ float s_rx[MF_PAD + MAX_RX + MF_PAD];   // zero padded both sides: no bounds in the tap loop
+    __shared__ float s_h[MF_PAD];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_pref;
+    __shared__ int s_k;
     __shared__ float s_pn[NPAY];
     __shared__ float s_win[MAX_WIN];
     __shared__ float s_d[NPAY];
-    __shared__ float s_dev[NPAY];
     __shared__ float s_score[4][2];
     __shared__ int   s_shift[4];
     __shared__ float s_stats[4];
@@ -155,8 +211,11 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         const double* fr = y + rec * T + st0;
         const int prefix = mem < PAYLOAD_START ? mem : PAYLOAD_START; // :327
         const int nfull = prefix + npl;
-        for (int i = tid; i < nfull; i += LLR_THREADS) s_rx[i] = (float)fr[PAYLOAD_START - prefix + i];
-        for (int i = tid; i < ntaps; i += LLR_THREADS) s_h[i] = tabs->taps[bi][i];
+        for (int i = tid; i < MF_PAD + MAX_RX + MF_PAD; i += LLR_THREADS) {
+            const int ii = i - MF_PAD;
+            s_rx[i] = (ii >= 0 && ii < nfull) ? (float)fr[PAYLOAD_START - prefix + ii] : 0.0f;
+        }
+        for (int i = tid; i < MF_PAD; i += LLR_THREADS) s_h[i] = (i < ntaps) ? tabs->taps[bi][i] : 0.0f;
         const int n = NPAY < npl ? NPAY : npl;                        // :337
         const uint8_t* pnr = pn_rows + rec * ES_PN_BYTES;
         const int pn_off = (variant == 0) ? PAYLOAD_START : 0;        // :306-312
@@ -182,14 +241,38 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         if (n / 4 < guard) guard = n / 4;
         if (guard >= n) guard = n / 4 > 0 ? n / 4 : 0;
 
-        // ---- matched filter window (:334): mf[j] = sum_i rx[i] h[j-i]
-        for (int w = tid; w < nwin; w += LLR_THREADS) {
-            const int jj = wstart + w;
-            int i0 = jj - (ntaps - 1); if (i0 < 0) i0 = 0;
-            const int i1 = jj < nfull - 1 ? jj : nfull - 1;
-            double acc = 0.0;
-            for (int i = i0; i <= i1; ++i) acc += (double)s_rx[i] * (double)s_h[jj - i];
-            s_win[w] = (float)acc;
+        // ---- matched filter window (:334): mf[j] = sum_i rx[i] h[j-i], i ascending (= tap k = j-i
+        // descending), float64 accumulation of exact float32 products, rounded once.  Each thread
+        // owns MF_R consecutive outputs and slides a register window over the samples they share;
+        // zero padding (samples and taps) only adds exact zeros.
+        {
+            const int k6 = ((ntaps + MF_R - 1) / MF_R) * MF_R;          // taps rounded up (extra taps are 0)
+            for (int w0 = tid * MF_R; w0 < nwin; w0 += LLR_THREADS * MF_R) {
+                const int jj0 = wstart + w0;
+                double acc[MF_R];
+                #pragma unroll
+                for (int r = 0; r < MF_R; ++r) acc[r] = 0.0;
+                // window x[r] = rx[jj0 + r - k] for the current tap k; walk k = k6-1 .. 0
+                const float* px = s_rx + MF_PAD + jj0 - (k6 - 1);
+                double x[2 * MF_R - 1];
+                #pragma unroll
+                for (int r = 0; r < MF_R - 1; ++r) x[r] = (double)px[r];
+                for (int kb = k6 - 1; kb >= 0; kb -= MF_R) {             // taps kb, kb-1, ..., kb-5
+                    #pragma unroll
+                    for (int u = 0; u < MF_R; ++u) x[MF_R - 1 + u] = (double)px[MF_R - 1 + u];
+                    #pragma unroll
+                    for (int u = 0; u < MF_R; ++u) {
+                        const double hk = (double)s_h[kb - u];
+                        #pragma unroll
+                        for (int r = 0; r < MF_R; ++r) acc[r] = __builtin_fma(x[u + r], hk, acc[r]);
+                    }
+                    #pragma unroll
+                    for (int r = 0; r < MF_R - 1; ++r) x[r] = x[MF_R + r];
+                    px += MF_R;
+                }
+                #pragma unroll
+                for (int r = 0; r < MF_R; ++r) if (w0 + r < nwin) s_win[w0 + r] = (float)acc[r];
+            }
         }
         __syncthreads();
 
@@ -227,17 +310,16 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         for (int i = tid; i < n; i += LLR_THREADS) s_d[i] = s_win[a0 + i] * s_pn[i];
         __syncthreads();
 
-        // ---- robust statistics on the tail (:395-404), wave 0
+        // ---- robust statistics on the tail (:395-404)
         const int toff = (n > guard + 8) ? guard : 0;
         const int nt = n - toff;
+        const float* tail = s_d + toff;
+        const float medv = block_median_f32(nt, [&](int i) { return tail[i]; }, s_hist, &s_pref, &s_k);
+        const float madv = block_median_f32(nt, [&](int i) { return __builtin_fabsf(tail[i] - medv); }, s_hist, &s_pref, &s_k);
         if (wv == 0) {
-            const float* tail = s_d + toff;
             PwPlan tp; pw_plan_build(tp, nt);
             const float mu = wave_pairwise_sum(tp, lane, [&](int i) { return tail[i]; }) / (float)nt;
-            const float medv = wave_median_f32(tail, nt, lane);
-            for (int i = lane; i < nt; i += 64) s_dev[i] = __builtin_fabsf(tail[i] - medv);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-            const double mad = (double)wave_median_f32(s_dev, nt, lane) + 1e-12;
+            const double mad = (double)madv + 1e-12;
             const float var = wave_pairwise_sum(tp, lane, [&](int i) { const float c = tail[i] - mu; return c * c; }) / (float)nt;
             const double sigma_mad = 1.4826 * mad;
             const double sigma_std = (double)__builtin_sqrtf(var) + 1e-12;
