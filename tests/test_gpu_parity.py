@@ -306,3 +306,55 @@ def test_scl_wide_matches_reference_golden(mode):
                 m = res.cand_metric[0].cpu().numpy()
                 assert np.array_equal(m, g[key]) if mode == "glibc" else np.allclose(m, g[key], rtol=1e-13, atol=0)
     eng.close()
+
+
+def test_config3_noisy_jittered_windows(engine, oracle):
+    """BASELINE config 3 shape: 65 536 records of W = 2048 samples, each holding a frame resampled
+    by a factor in [0.95, 1.05] (linear interpolation, seed 3) at a random offset, plus AWGN at
+    -15 dB SNR (seed 4).  512 distinct windows are generated and tiled to 65 536 records; checks:
+    spot rows equal the oracle bit for bit (sync, LLR at the detected peak, SCL-8), and every copy
+    of a window gives identical results wherever it sits in the batch."""
+    from scipy.signal import lfilter  # noqa: F401  (scipy present on the GPU box; only numpy is used below)
+    U, B, W = 512, 65536, 2048
+    frames, band, pn = _workload(U)
+    rng3, rng4 = np.random.default_rng(3), np.random.default_rng(4)
+    win = np.zeros((U, W), np.float32)
+    for i in range(U):
+        fac = rng3.uniform(0.95, 1.05)
+        m = int(np.floor((1215 - 1) / fac)) + 1
+        res = np.interp(np.arange(m) * fac, np.arange(1215), frames[i]).astype(np.float32)
+        off = int(rng3.integers(0, W - m + 1))
+        win[i, off:off + m] = res
+        rms = float(np.sqrt(np.mean(res.astype(np.float64) ** 2)))
+        win[i] += rng4.normal(0.0, rms * 10 ** (15 / 20), W).astype(np.float32)
+    reps = B // U
+    f = torch.from_numpy(win).to(engine.device).repeat(reps, 1)
+    b = torch.from_numpy(band).to(engine.device).repeat(reps)
+    p = torch.from_numpy(pn).to(engine.device).repeat(reps, 1)
+    sy = engine.sync(f, b, keep_corr=False)
+    start = sy.peaks[:, 0].clamp(min=0).contiguous()
+    llr, bs, _ = engine.llr(sy.y, b, p, start=start, want_diag=True)
+    res = engine.scl(llr, list_size=8, skip_if_hard_ok=True)
+    # position independence
+    for t in (sy.thr, sy.peaks, sy.npeaks, llr, bs, res.cand_info, res.cand_metric, res.ncand, res.hard_info):
+        v = t.reshape(reps, U, -1)
+        assert bool(torch.all(v == v[0:1])), "result depends on the position in the batch"
+    # spot parity with the oracle
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    y = sy.y[:U].cpu().numpy(); thr = sy.thr[:U].cpu().numpy(); pk = sy.peaks[:U].cpu().numpy(); npk = sy.npeaks[:U].cpu().numpy()
+    L = llr[:U].cpu().numpy()
+    for i in range(0, U, 37):
+        bi = band[i]
+        yy = oracle.lfilter(ba[bi, :9], ba[bi, 9:], win[i])
+        assert np.array_equal(yy, y[i])
+        corr = oracle.ncc(yy, tpl[bi]); th, _, _ = oracle.cfar_threshold(corr)
+        peaks, tot, fb = oracle.pick_peaks(corr, th)
+        k = int(npk[i]) & 0xFFFF
+        assert th == thr[i] and bool(npk[i] >> 30) == fb and list(pk[i, :k]) == list(peaks[:k])
+        st = int(peaks[0])
+        o, obs, _, _ = oracle.llr(yy[st:st + 1215], np.unpackbits(pn[i])[191:1215], taps[bi, :ntaps[bi]])
+        assert np.array_equal(o, L[i])
+        nn, ci, cm, cc = oracle.scl_list(o.astype(np.float64), 8)
+        if int(res.ncand[i]):
+            assert np.array_equal(np.packbits(ci, axis=1), res.cand_info[i].cpu().numpy())
+            assert np.array_equal(cm, res.cand_metric[i].cpu().numpy())
