@@ -13,7 +13,8 @@ range [0, 1024 N) (weak scaling); rank 0 derives the key/PN schedule and broadca
 RCCL before the timed region; the data path has no collective.
 
 Extra objects in the JSON line:
-  roofline     the xcorr kernel (the HBM-graded kernel): algorithmic bytes per launch
+  roofline     es_xcorr32_kernel (the HBM-graded correlation kernel: float32 screen whose decisions are
+               settled exactly in float64 by es_pick_exact_kernel): algorithmic bytes per launch
                (9 472 B/frame: SURVEY.md section 8d) / its mean duration measured with HIP events
                on the launch stream inside the timed region, against the 8 TB/s HBM peak.
   cpu_baseline the CPU oracle (C restatement of the reference, kind "port") timed on this host.
@@ -117,17 +118,18 @@ def main() -> None:
     main = torch.cuda.current_stream(dev)
 
     def step(k=None):
-        # band-pass -> xcorr on the main stream, then two independent branches: pick on a side
-        # stream, (llr -> scl) on the main stream; joined before the step ends.
-        y = eng.bpf(frames_d, band_d)
+        # band-pass (y64 + y32) -> float32 correlation screen on the main stream, then two independent
+        # branches: exact peak picking (float64 fix-ups) on a side stream, (llr -> scl) on the main
+        # stream; joined before the step ends.  thr / peaks are bit-identical to the float64 path.
+        y, y32 = eng.bpf2(frames_d, band_d)
         if k is not None:
             ev[k][0].record()
-        corr = eng.xcorr(y, band_d)
+        corr32 = eng.xcorr32(y32, band_d)
         if k is not None:
             ev[k][1].record()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            thr, peaks, npeaks = eng.pick(corr)
+            thr, peaks, npeaks, flags = eng.pick_exact(corr32, y, band_d)
         llr = eng.llr(y, band_d, pn_d, variant=0)
         res = eng.scl(llr, list_size=L, skip_if_hard_ok=True)
         main.wait_stream(side)
@@ -160,13 +162,13 @@ def main() -> None:
     if rank == 0:
         Bb = 65536
         reps = -(-Bb // B)
-        yb = eng.bpf(frames_d.repeat(reps, 1)[:Bb].contiguous(), band_d.repeat(reps)[:Bb].contiguous())
         bb = band_d.repeat(reps)[:Bb].contiguous()
-        eng.xcorr(yb, bb)
+        _, yb = eng.bpf2(frames_d.repeat(reps, 1)[:Bb].contiguous(), bb)
+        eng.xcorr32(yb, bb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            cb = eng.xcorr(yb, bb)
+            cb = eng.xcorr32(yb, bb)
         e1.record()
         torch.cuda.synchronize()
         big_ms = e0.elapsed_time(e1) / 5
@@ -182,8 +184,8 @@ def main() -> None:
         # the gfx950 guide prescribes, WRITE_SIZE as read); measured on the 1024-record launch.
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_xcorr_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)["es_xcorr_kernel"]["B=1024 (C2 launch)"]
+            with open(os.path.join(ROOT, "profiles", "r01_xcorr32_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)["es_xcorr32_kernel"]["B=1024 (C2 launch)"]
             if B == 1024:
                 traffic = pmc["hbm_bytes_per_launch"]
         except Exception:
@@ -198,13 +200,13 @@ def main() -> None:
                        "frames_per_gpu": B, "list_size": L, "frame_len": 1215, "fs": 48000,
                        "sharding": f"{world} x {B} frames, schedule broadcast from rank 0",
                        "sync_offsets_ok": ok_sync, "frames_through_list_decoder": listed},
-            "roofline": {"kernel": "es_xcorr_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "es_xcorr32_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": xcorr_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_FRAME * B},
-            "roofline_c3": {"kernel": "es_xcorr_kernel", "bound": "hbm", "achieved": big, "peak": HBM_PEAK_GBS,
+            "roofline_c3": {"kernel": "es_xcorr32_kernel", "bound": "hbm", "achieved": big, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": big / HBM_PEAK_GBS, "launch_ms": big_ms,
                             "note": "same kernel, 65 536-record launch (BASELINE config 3 size), outside the timed "
-                                    "region; actual HBM traffic is 2x the algorithmic figure (float64 in/out)"},
+                                    "region; float32 in / float32 out = the algorithmic 9 472 B per record"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_h, band_d.cpu().numpy(), pn_d.cpu().numpy(), L)

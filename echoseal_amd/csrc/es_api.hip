@@ -90,7 +90,7 @@ int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float*
         const double a0 = ba[b * 18 + 9];
         if (a0 == 0.0) return fail(ctx, ES_EINVAL, "es_set_tables: a[0] is zero");
         for (int k = 0; k < 18; ++k) h.ba[b][k] = ba[b * 18 + k] / a0;    // SciPy normalises by a[0]
-        for (int k = 0; k < ES_PRE_L; ++k) h.tpl[b][k] = tpl[b * ES_PRE_L + k];
+        for (int k = 0; k < ES_PRE_L; ++k) { h.tpl[b][k] = tpl[b * ES_PRE_L + k]; h.tpl32[b][k] = (float)tpl[b * ES_PRE_L + k]; }
         if (ntaps[b] < 1 || ntaps[b] > ES_MAX_TAPS) return fail(ctx, ES_EINVAL, "es_set_tables: ntaps out of range");
         h.ntaps[b] = ntaps[b];
         for (int k = 0; k < ntaps[b]; ++k) h.taps[b][k] = taps[b * ES_MAX_TAPS + k];
@@ -127,7 +127,60 @@ int es_bpf_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int 
     if (B == 0 || T == 0) return ES_OK;
     if (!frames_dev || !band_dev || !y_dev) return fail(ctx, ES_EINVAL, "es_bpf_batch: null pointer");
     DeviceGuard g(ctx->device);
-    return es_launch_bpf(ctx, frames_dev, dtype, B, T, band_dev, y_dev, (hipStream_t)stream);
+    return es_launch_bpf(ctx, frames_dev, dtype, B, T, band_dev, y_dev, nullptr, (hipStream_t)stream);
+}
+
+int es_bpf2_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
+                  const uint8_t* band_dev, double* y_dev, float* y32_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0 || T < 0) return fail(ctx, ES_EINVAL, "es_bpf2_batch: negative size");
+    if (dtype != ES_DTYPE_F32 && dtype != ES_DTYPE_I16) return fail(ctx, ES_EINVAL, "es_bpf2_batch: dtype must be f32 or i16");
+    if (B == 0 || T == 0) return ES_OK;
+    if (!frames_dev || !band_dev || !y_dev || !y32_dev) return fail(ctx, ES_EINVAL, "es_bpf2_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_bpf(ctx, frames_dev, dtype, B, T, band_dev, y_dev, y32_dev, (hipStream_t)stream);
+}
+
+int es_xcorr32_batch(es_ctx* ctx, const float* y32_dev, int64_t B, int T, const uint8_t* band_dev,
+                     float* corr32_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0) return fail(ctx, ES_EINVAL, "es_xcorr32_batch: negative size");
+    if (T < ES_PRE_L) return fail(ctx, ES_EINVAL, "es_xcorr32_batch: record shorter than the 63-chip template");
+    if (B == 0) return ES_OK;
+    if (!y32_dev || !band_dev || !corr32_dev) return fail(ctx, ES_EINVAL, "es_xcorr32_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_xcorr32(ctx, y32_dev, B, T, band_dev, corr32_dev, (hipStream_t)stream);
+}
+
+int es_pick_exact_batch(es_ctx* ctx, const float* corr32_dev, const double* y_dev, int64_t B, int T,
+                        const uint8_t* band_dev, double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev,
+                        uint8_t* flags_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0) return fail(ctx, ES_EINVAL, "es_pick_exact_batch: negative size");
+    if (T < ES_PRE_L) return fail(ctx, ES_EINVAL, "es_pick_exact_batch: record shorter than the 63-chip template");
+    if (B == 0) return ES_OK;
+    if (!corr32_dev || !y_dev || !band_dev || !thr_dev || !peaks_dev || !npeaks_dev || !flags_dev)
+        return fail(ctx, ES_EINVAL, "es_pick_exact_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    const int n_lags = T - (ES_PRE_L - 1);
+    /* float64 workspace for the (rare) records the float32 screen cannot settle; grows monotonically,
+       so after a warm-up call nothing is allocated on the launch path */
+    const size_t need = (size_t)B * n_lags * sizeof(double);
+    if (need > ctx->ws_corr_bytes) {
+        if (ctx->d_ws_corr) ES_HIP_CHECK(ctx, hipFree(ctx->d_ws_corr));
+        ctx->d_ws_corr = nullptr; ctx->ws_corr_bytes = 0;
+        ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_ws_corr, need));
+        ctx->ws_corr_bytes = need;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = es_launch_pick_exact(ctx, corr32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, st);
+    if (rc) return rc;
+    rc = es_launch_xcorr_flagged(ctx, y_dev, B, T, band_dev, ctx->d_ws_corr, flags_dev, st);
+    if (rc) return rc;
+    return es_launch_pick_flagged(ctx, ctx->d_ws_corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, flags_dev, st);
 }
 
 int es_xcorr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const uint8_t* band_dev,

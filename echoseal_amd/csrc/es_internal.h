@@ -14,6 +14,7 @@ struct es_band_tables {
     double ba[ES_NBANDS][18];                         /* b[0..8], a[0..8] (already divided by a0) */
     double tpl[ES_NBANDS][64];                        /* 63 taps + pad */
     float  taps[ES_NBANDS][ES_MAX_TAPS];
+    float  tpl32[ES_NBANDS][64];                      /* template rounded to float32 (screening kernel) */
     int32_t ntaps[ES_NBANDS];
 };
 
@@ -57,7 +58,14 @@ int es_launch_scl(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int
                   uint8_t* cand_ok, int32_t* ncand, hipStream_t st);
 int es_launch_polar_encode(es_ctx* ctx, const uint8_t* info, int64_t B, uint8_t* code, hipStream_t st);
 int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, const uint8_t* band,
-                  double* y, hipStream_t st);
+                  double* y, float* y32, hipStream_t st);
+int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uint8_t* band, float* corr32, hipStream_t st);
+int es_launch_pick_exact(es_ctx* ctx, const float* corr32, const double* y, int64_t B, int T, const uint8_t* band,
+                         double* thr, int32_t* peaks, int32_t* npeaks, uint8_t* flags, hipStream_t st);
+int es_launch_xcorr_flagged(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
+                            const uint8_t* flags, hipStream_t st);
+int es_launch_pick_flagged(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
+                           int32_t* npeaks, const uint8_t* flags, hipStream_t st);
 int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
                     hipStream_t st);
 int es_launch_pick(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,

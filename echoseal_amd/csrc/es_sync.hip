@@ -34,7 +34,7 @@ constexpr int BPF_WAVES = 2;        // waves per block (LDS: 2 x (8.4 + 16.9) KB
 template <bool I16>
 __global__ __launch_bounds__(64 * BPF_WAVES) void es_bpf_kernel(const void* __restrict__ frames,
         long long B, int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
-        double* __restrict__ y)
+        double* __restrict__ y, float* __restrict__ y32)
 {
     __shared__ float  s_x[BPF_WAVES][64][BPF_TT + 1];
     __shared__ double s_y[BPF_WAVES][64][BPF_TT + 1];
@@ -77,7 +77,11 @@ __global__ __launch_bounds__(64 * BPF_WAVES) void es_bpf_kernel(const void* __re
         #pragma unroll 4
         for (int r = half; r < 64; r += 2) {
             const long long rr = rec0 + r;
-            if (rr < B && t0 + col < T) y[rr * T + t0 + col] = s_y[wv][r][col];
+            if (rr < B && t0 + col < T) {
+                const double v = s_y[wv][r][col];
+                y[rr * T + t0 + col] = v;
+                if (y32) y32[rr * T + t0 + col] = (float)v;
+            }
         }
         wave_fence_lds();
     }
@@ -114,7 +118,7 @@ __device__ __forceinline__ double dpp_quad_f64(double v, const int ctrl_bcast0)
 template <bool I16>
 __global__ __launch_bounds__(64 * BQ_WAVES) void es_bpf_quad_kernel(const void* __restrict__ frames,
         long long B, int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
-        double* __restrict__ y)
+        double* __restrict__ y, float* __restrict__ y32)
 {
     __shared__ float  s_x[BQ_WAVES][BQ_RECS][BQ_TT + 1];
     __shared__ double s_y[BQ_WAVES][BQ_RECS][BQ_TT + 1];
@@ -180,7 +184,11 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void es_bpf_quad_kernel(const void* 
         #pragma unroll
         for (int i = 0; i < BQ_RECS / 2; ++i) {
             const long long rr = rec0 + 2 * i + half;
-            if (rr < B && t0 + col < T) y[rr * T + t0 + col] = s_y[wv][2 * i + half][col];
+            if (rr < B && t0 + col < T) {
+                const double v = s_y[wv][2 * i + half][col];
+                y[rr * T + t0 + col] = v;
+                if (y32) y32[rr * T + t0 + col] = (float)v;   // what _llr and the f32 correlation screen read
+            }
         }
         wave_fence_lds();
     }
@@ -203,7 +211,7 @@ constexpr int XC_WAVES = 4;
 
 __global__ __launch_bounds__(64 * XC_WAVES) void es_xcorr_kernel(const double* __restrict__ y, long long B,
         int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
-        double* __restrict__ corr)
+        double* __restrict__ corr, const uint8_t* __restrict__ only_flagged)
 {
     __shared__ double s_buf[XC_WAVES][XC_NS + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -214,10 +222,17 @@ __global__ __launch_bounds__(64 * XC_WAVES) void es_xcorr_kernel(const double* _
     const long long stride = (long long)gridDim.x * XC_WAVES;
     for (long long item = (long long)blockIdx.x * XC_WAVES + wv; item < n_items; item += stride) {
         const long long rec = item / nseg;
+        if (only_flagged && !only_flagged[rec]) continue;      // redo pass: only records the f32 screen gave up on
         const int lag0 = (int)(item % nseg) * XC_SEG;
         const double* yr = y + rec * T + lag0;
         const int nsamp = (T - lag0 < XC_NS) ? T - lag0 : XC_NS;
-        for (int i = lane; i < XC_NS; i += 64) s[i] = (i < nsamp) ? yr[i] : 0.0;
+        {   // all 20 row loads are issued before the first one is consumed (one HBM round trip, not 20)
+            double stage[(XC_NS + 63) / 64];
+            #pragma unroll
+            for (int u = 0; u < (XC_NS + 63) / 64; ++u) { const int i = lane + 64 * u; stage[u] = (i < nsamp) ? yr[i] : 0.0; }
+            #pragma unroll
+            for (int u = 0; u < (XC_NS + 63) / 64; ++u) { const int i = lane + 64 * u; if (i < XC_NS) s[i] = stage[u]; }
+        }
         // wave-uniform band index -> template taps come through scalar loads
         const double* tpl = tabs->tpl[__builtin_amdgcn_readfirstlane((int)band[rec])];
         wave_fence_lds();
@@ -354,7 +369,8 @@ __device__ double block_median(const double* v, int n, double center, uint32_t* 
 
 template <bool IN_LDS>
 __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __restrict__ corr, long long B,
-        int n, double* __restrict__ thr_out, int32_t* __restrict__ peaks, int32_t* __restrict__ npeaks)
+        int n, double* __restrict__ thr_out, int32_t* __restrict__ peaks, int32_t* __restrict__ npeaks,
+        const uint8_t* __restrict__ only_flagged)
 {
     __shared__ double s_row[IN_LDS ? PK_LDS_N : 1];
     __shared__ uint32_t s_hist[256];
@@ -368,6 +384,7 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
     const int min_distance = ES_FRAME_LEN / 2;        // 607
 
     for (long long rec = blockIdx.x; rec < B; rec += gridDim.x) {
+        if (only_flagged && !only_flagged[rec]) continue;
         const double* cg = corr + rec * n;
         const double* c = cg;
         if (IN_LDS) {
@@ -454,17 +471,17 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
 }  // namespace
 
 int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, const uint8_t* band,
-                  double* y, hipStream_t st)
+                  double* y, float* y32, hipStream_t st)
 {
     if (B < 262144) {                               // four lanes per record: 4x the waves
         const long long per_block = (long long)BQ_RECS * BQ_WAVES;
         const unsigned blocks = (unsigned)((B + per_block - 1) / per_block);
         if (dtype == ES_DTYPE_I16)
             hipLaunchKernelGGL(es_bpf_quad_kernel<true>, dim3(blocks), dim3(64 * BQ_WAVES), 0, st, frames,
-                               (long long)B, T, band, ctx->d_tables, y);
+                               (long long)B, T, band, ctx->d_tables, y, y32);
         else
             hipLaunchKernelGGL(es_bpf_quad_kernel<false>, dim3(blocks), dim3(64 * BQ_WAVES), 0, st, frames,
-                               (long long)B, T, band, ctx->d_tables, y);
+                               (long long)B, T, band, ctx->d_tables, y, y32);
         ES_HIP_CHECK(ctx, hipGetLastError());
         return ES_OK;
     }
@@ -472,16 +489,25 @@ int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, 
     const unsigned blocks = (unsigned)((B + recs_per_block - 1) / recs_per_block);
     if (dtype == ES_DTYPE_I16)
         hipLaunchKernelGGL(es_bpf_kernel<true>, dim3(blocks), dim3(64 * BPF_WAVES), 0, st, frames,
-                           (long long)B, T, band, ctx->d_tables, y);
+                           (long long)B, T, band, ctx->d_tables, y, y32);
     else
         hipLaunchKernelGGL(es_bpf_kernel<false>, dim3(blocks), dim3(64 * BPF_WAVES), 0, st, frames,
-                           (long long)B, T, band, ctx->d_tables, y);
+                           (long long)B, T, band, ctx->d_tables, y, y32);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
 
+int es_launch_xcorr_flagged(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
+                            const uint8_t* flags, hipStream_t st);
+
 int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
                     hipStream_t st)
+{
+    return es_launch_xcorr_flagged(ctx, y, B, T, band, corr, nullptr, st);
+}
+
+int es_launch_xcorr_flagged(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
+                            const uint8_t* flags, hipStream_t st)
 {
     const int n_lags = T - (ES_PRE_L - 1);
     const long long nseg = (n_lags + XC_SEG - 1) / XC_SEG;
@@ -489,7 +515,7 @@ int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_
     const long long cap = (long long)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(es_xcorr_kernel, dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y, (long long)B,
-                       T, band, ctx->d_tables, corr);
+                       T, band, ctx->d_tables, corr, flags);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
@@ -497,15 +523,21 @@ int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_
 int es_launch_pick(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
                    int32_t* npeaks, hipStream_t st)
 {
+    return es_launch_pick_flagged(ctx, corr, B, n_lags, thr, peaks, npeaks, nullptr, st);
+}
+
+int es_launch_pick_flagged(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
+                           int32_t* npeaks, const uint8_t* flags, hipStream_t st)
+{
     long long blocks = B;
     const long long cap = (long long)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
     if (n_lags <= PK_LDS_N)
         hipLaunchKernelGGL(es_pick_kernel<true>, dim3((unsigned)blocks), dim3(PK_THREADS), 0, st, corr,
-                           (long long)B, n_lags, thr, peaks, npeaks);
+                           (long long)B, n_lags, thr, peaks, npeaks, flags);
     else
         hipLaunchKernelGGL(es_pick_kernel<false>, dim3((unsigned)blocks), dim3(PK_THREADS), 0, st, corr,
-                           (long long)B, n_lags, thr, peaks, npeaks);
+                           (long long)B, n_lags, thr, peaks, npeaks, flags);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }

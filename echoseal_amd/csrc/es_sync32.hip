@@ -1,0 +1,408 @@
+// es_sync32.hip -- float32 correlation SCREEN with float64 exact fix-ups.
+//
+// Why: sync offsets must equal the float64 reference exactly, but a float64 correlation kernel is
+// bound by FP64 vector issue (es_sync.hip: ~25 % of the HBM roofline at best).  Almost none of the
+// 1153 correlation values of a record ever matter at full precision: only the ones next to a
+// decision boundary (the median, the MAD, the threshold, a local maximum).  So:
+//
+//   es_xcorr32_kernel   y32 (float32, written by the band-pass next to y64) -> corr32 (float32).
+//                       4 860 B in, 4 612 B out per record: the traffic SURVEY.md section 8(d)
+//                       prices the correlation kernel at.  FP32 FMAs, taps in scalar registers.
+//   es_pick_exact_kernel  works on corr32 with a rigorous error bound DELTA (|corr32 - corr64| <=
+//                       DELTA), and re-evaluates in float64 -- with exactly the arithmetic of
+//                       es_xcorr_kernel / oracle/c/eso_dsp.c -- every value that lies within reach
+//                       of a decision: the order statistics' neighbourhoods (order statistics are
+//                       1-Lipschitz in the sup norm, so the exact k-th value is the (k - #below)-th
+//                       of the band [m32 - 2 DELTA, m32 + 2 DELTA]), the threshold crossers and the
+//                       rivals of a local maximum.  thr / peaks / npeaks come out bit-identical to
+//                       the all-float64 path; records with too many ambiguous values (constant
+//                       signals, exact repeats) are flagged and redone by the float64 kernels.
+//
+// Error bound: inputs rounded to f32 (2 x 2^-24 relative), 63-term FMA chain (63 x 2^-24 of
+// sum|y||tpl| <= e_y by Cauchy-Schwarz, |tpl| = 1), energy and sqrt (~2e-6 relative), approximate
+// rcp/sqrt (1e-6): |corr32 - corr64| < 8e-6 for |corr| <= 1.  DELTA = 3e-5.
+#include "es_internal.h"
+
+namespace {
+
+__device__ __forceinline__ void wave_fence_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int XC_R = 19;                            // must equal es_sync.hip / oracle XC_CHUNK
+constexpr int XC_SEG = 64 * XC_R;
+constexpr int XC_NS = XC_SEG + ES_PRE_L - 1;
+constexpr int XC_WAVES = 4;
+constexpr double DELTA = 3e-5;
+
+// ------------------------------------------------------------------------------------ xcorr32
+__global__ __launch_bounds__(64 * XC_WAVES) void es_xcorr32_kernel(const float* __restrict__ y, long long B,
+        int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
+        float* __restrict__ corr)
+{
+    __shared__ float s_buf[XC_WAVES][XC_NS + 2];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: item, record, band are scalar
+    float* s = s_buf[wv];
+    const int n_lags = T - (ES_PRE_L - 1);
+    const int nseg = (n_lags + XC_SEG - 1) / XC_SEG;
+    const long long n_items = B * nseg;
+    const long long stride = (long long)gridDim.x * XC_WAVES;
+    // item -> (record, segment) with 32-bit arithmetic (the launcher keeps n_items < 2^31); nseg is 1
+    // for frame-sized records, so the division disappears on the hot path
+    auto rec_of = [&](unsigned it) { return nseg == 1 ? it : it / (unsigned)nseg; };
+    constexpr int NST = (XC_NS + 63) / 64;
+    float stage[NST];                               // next record's samples, in flight while this one is computed
+    int bi_next = 0;
+    auto prefetch = [&](unsigned it) {
+        const long long r = rec_of(it);
+        const int l0 = (nseg == 1) ? 0 : (int)(it - (unsigned)r * (unsigned)nseg) * XC_SEG;
+        const float* src = y + r * T + l0;
+        const int ns = (T - l0 < XC_NS) ? T - l0 : XC_NS;
+        #pragma unroll
+        for (int u = 0; u < NST; ++u) { const int i = lane + 64 * u; stage[u] = (i < ns) ? src[i] : 0.0f; }
+        bi_next = (int)band[r];
+    };
+    unsigned item = (unsigned)(blockIdx.x * XC_WAVES + wv);
+    if (item < (unsigned)n_items) prefetch(item);
+    for (; item < (unsigned)n_items; item += (unsigned)stride) {
+        const long long rec = rec_of(item);
+        const int lag0 = (nseg == 1) ? 0 : (int)(item - (unsigned)rec * (unsigned)nseg) * XC_SEG;
+        const int bi = __builtin_amdgcn_readfirstlane(bi_next);
+        #pragma unroll
+        for (int u = 0; u < NST; ++u) { const int i = lane + 64 * u; if (i < XC_NS) s[i] = stage[u]; }
+        if (item + (unsigned)stride < (unsigned)n_items) prefetch(item + (unsigned)stride);
+        const float* tpg = tabs->tpl32[bi];
+        float tp[ES_PRE_L];                                  // loaded once per record, kept in SGPRs
+        #pragma unroll
+        for (int k = 0; k < ES_PRE_L; ++k) tp[k] = tpg[k];
+        wave_fence_lds();
+
+        const float* w = s + lane * XC_R;
+        float num[XC_R], en[XC_R], sq_head[XC_R - 1];
+        #pragma unroll
+        for (int r = 0; r < XC_R; ++r) num[r] = 0.0f;
+        float core = 0.0f, tail_run = 0.0f;
+        #define XC32_FMAS(m, v)                                                                 \
+            _Pragma("unroll") for (int r = 0; r < XC_R; ++r) {                                  \
+                const int k = (m) - r;                                                          \
+                if (k >= 0 && k < ES_PRE_L) num[r] = __builtin_fmaf((v), tp[k], num[r]);        \
+            }
+        #pragma unroll
+        for (int m = 0; m < XC_R - 1; ++m) { const float v = w[m]; sq_head[m] = v * v; XC32_FMAS(m, v) }
+        en[XC_R - 1] = 0.0f;
+        #pragma unroll
+        for (int r = XC_R - 2; r >= 0; --r) en[r] = en[r + 1] + sq_head[r];
+        #pragma unroll
+        for (int m = XC_R - 1; m < ES_PRE_L; ++m) { const float v = w[m]; core = __builtin_fmaf(v, v, core); XC32_FMAS(m, v) }
+        #pragma unroll
+        for (int r = 0; r < XC_R; ++r) en[r] = en[r] + core;
+        #pragma unroll
+        for (int m = ES_PRE_L; m < ES_PRE_L - 1 + XC_R; ++m) {
+            const float v = w[m];
+            tail_run = __builtin_fmaf(v, v, tail_run);
+            en[m - (ES_PRE_L - 1)] = en[m - (ES_PRE_L - 1)] + tail_run;
+            XC32_FMAS(m, v)
+        }
+        #undef XC32_FMAS
+        wave_fence_lds();
+        #pragma unroll
+        for (int r = 0; r < XC_R; ++r)
+            s[lane * XC_R + r] = num[r] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(en[r]) + 1e-12f);
+        wave_fence_lds();
+        const int nl = (n_lags - lag0 < XC_SEG) ? n_lags - lag0 : XC_SEG;
+        float* cr = corr + rec * n_lags + lag0;
+        for (int i = lane; i < nl; i += 64) cr[i] = s[i];
+        wave_fence_lds();
+    }
+}
+
+// ------------------------------------------------------------------------------------ exact value
+// corr64 of one lag, bit-identical to es_xcorr_kernel / eso_ncc: FMA chain over ascending taps;
+// energy = (head + core) + tail over the 19-lag chunk the lag belongs to.
+__device__ double corr64_at(const double* __restrict__ yr, int i, const double* __restrict__ tpl)
+{
+    const int c = i - i % XC_R;
+    double num = 0.0;
+    for (int k = 0; k < ES_PRE_L; ++k) num = __builtin_fma(yr[i + k], tpl[k], num);
+    double core = 0.0;
+    for (int j = c + XC_R - 1; j <= c + ES_PRE_L - 1; ++j) core = core + yr[j] * yr[j];
+    double head = 0.0;
+    for (int j = c + XC_R - 2; j >= i; --j) head = head + yr[j] * yr[j];
+    double tail = 0.0;
+    for (int j = c + ES_PRE_L; j <= i + ES_PRE_L - 1; ++j) tail = tail + yr[j] * yr[j];
+    const double en = (head + core) + tail;
+    return num / (__builtin_sqrt(en) + 1e-12);
+}
+
+// ------------------------------------------------------------------------------------ pick (exact)
+constexpr int PX_THREADS = 256;
+constexpr int PX_MAXN = 4096;
+constexpr int PX_CAP = 192;                         // ambiguous values a record may have before it is flagged
+
+__device__ __forceinline__ uint32_t f32_key(float x)
+{
+    uint32_t b; __builtin_memcpy(&b, &x, 4);
+    return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k)
+{
+    const uint32_t b = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+    float x; __builtin_memcpy(&x, &b, 4); return x;
+}
+
+struct PxShared {
+    float    row[PX_MAXN];
+    uint32_t hist[256];
+    uint32_t pref;
+    int      k;
+    int      list[PX_CAP];
+    double   val[PX_CAP];
+    double   res[2];
+    int      cnt, below, flag;
+    double   cand_val;
+    int      taken[8];
+};
+
+// k-th smallest 32-bit key of key(i), i in [0,n): 4 passes of 8 bits (LDS histogram + wave scan)
+template <typename F>
+__device__ uint32_t px_select(PxShared& S, int n, int k, F key)
+{
+    uint32_t prefix = 0;
+    int kk = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        S.hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t himask = (shift == 24) ? 0u : (~0u << (shift + 8));
+        for (int i = threadIdx.x; i < n; i += PX_THREADS) {
+            const uint32_t kx = key(i);
+            if ((kx & himask) == prefix) atomicAdd(&S.hist[(kx >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        {
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            const uint32_t h = S.hist[threadIdx.x];
+            uint32_t incl = h;
+            #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            __syncthreads();
+            if (lane == 63) S.hist[wv] = incl;
+            __syncthreads();
+            uint32_t basec = 0;
+            for (int w = 0; w < wv; ++w) basec += S.hist[w];
+            incl += basec;
+            const uint32_t excl = incl - h;
+            if ((int)excl <= kk && kk < (int)incl) { S.k = kk - (int)excl; S.pref = prefix | ((uint32_t)threadIdx.x << shift); }
+        }
+        __syncthreads();
+        prefix = S.pref; kk = S.k;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// Exact order statistics k_lo <= k_hi of exact(i) given a screen(i) with |screen - exact| <= d:
+// band = screen within [m_lo - 2d, m_hi + 2d]; exact values of the band are ranked by counting.
+// Returns false (record must be flagged) when the band does not fit.  Results in S.res[0..1].
+template <typename FS, typename FE>
+__device__ bool px_exact_stats(PxShared& S, int n, int k_lo, int k_hi, double d, FS screen, FE exact)
+{
+    auto key = [&](int i) { return f32_key((float)screen(i)); };
+    const float m_lo = key_f32(px_select(S, n, k_lo, key));
+    const float m_hi = (k_hi == k_lo) ? m_lo : key_f32(px_select(S, n, k_hi, key));
+    // (float) rounding of the screen value costs at most 2^-24 relative: folded into the margin
+    const double lo = (double)m_lo - 2.0 * d - 1e-6 * __builtin_fabs((double)m_lo);
+    const double hi = (double)m_hi + 2.0 * d + 1e-6 * __builtin_fabs((double)m_hi);
+    if (threadIdx.x == 0) { S.cnt = 0; S.below = 0; }
+    __syncthreads();
+    int below = 0;
+    for (int i = threadIdx.x; i < n; i += PX_THREADS) {
+        const double v = screen(i);
+        if (v < lo) ++below;
+        else if (v <= hi) { const int slot = atomicAdd(&S.cnt, 1); if (slot < PX_CAP) S.list[slot] = i; }
+    }
+    atomicAdd(&S.below, below);
+    __syncthreads();
+    const int nb = S.cnt;
+    if (nb > PX_CAP) return false;
+    if ((int)threadIdx.x < nb) S.val[threadIdx.x] = exact(S.list[threadIdx.x]);
+    __syncthreads();
+    const int r_lo = k_lo - S.below, r_hi = k_hi - S.below;
+    if ((int)threadIdx.x < nb) {
+        const double v = S.val[threadIdx.x];
+        int less = 0, eq = 0;
+        for (int j = 0; j < nb; ++j) { less += S.val[j] < v; eq += S.val[j] == v; }
+        if (less <= r_lo && r_lo < less + eq) S.res[0] = v;
+        if (less <= r_hi && r_hi < less + eq) S.res[1] = v;
+    }
+    __syncthreads();
+    return true;
+}
+
+__global__ __launch_bounds__(PX_THREADS) void es_pick_exact_kernel(const float* __restrict__ corr32,
+        const double* __restrict__ y, long long B, int T, const uint8_t* __restrict__ band,
+        const es_band_tables* __restrict__ tabs, double* __restrict__ thr_out, int32_t* __restrict__ peaks,
+        int32_t* __restrict__ npeaks, uint8_t* __restrict__ flags)
+{
+    __shared__ PxShared S;
+    const int n = T - (ES_PRE_L - 1);
+    const int min_distance = ES_FRAME_LEN / 2;
+    for (long long rec = blockIdx.x; rec < B; rec += gridDim.x) {
+        const float* cg = corr32 + rec * n;
+        const double* yr = y + rec * T;
+        const double* tpl = tabs->tpl[band[rec]];
+        int bad = 0;
+        for (int i = threadIdx.x; i < n; i += PX_THREADS) {
+            const float v = cg[i];
+            S.row[i] = v;
+            bad |= !(__builtin_fabsf(v) < 1e30f);                       // inf / nan / absurd: screen unusable
+        }
+        if (__syncthreads_or(bad)) {
+            if (threadIdx.x == 0) flags[rec] = 1;                        // reason 1: non-finite screen
+            __syncthreads();
+            continue;
+        }
+        const float* c = S.row;
+        auto exact_corr = [&](int i) { return corr64_at(yr, i, tpl); };
+        const int k_hi = n / 2, k_lo = (n & 1) ? n / 2 : n / 2 - 1;
+
+        // ---- median (exact)
+        bool ok = px_exact_stats(S, n, k_lo, k_hi, DELTA, [&](int i) { return (double)c[i]; }, exact_corr);
+        double med = 0.0, mad = 0.0;
+        int why = 2;                                                     // reason 2: median band too wide
+        if (ok) {
+            why = 3;                                                     // reason 3: MAD band too wide
+            med = (n & 1) ? S.res[0] : (S.res[0] + S.res[1]) / 2.0;
+            __syncthreads();
+            // ---- MAD (exact): |corr64 - med| screened by |corr32 - med|
+            ok = px_exact_stats(S, n, k_lo, k_hi, DELTA, [&](int i) { return __builtin_fabs((double)c[i] - med); },
+                                [&](int i) { return __builtin_fabs(corr64_at(yr, i, tpl) - med); });
+            if (ok) mad = ((n & 1) ? S.res[0] : (S.res[0] + S.res[1]) / 2.0) + 1e-12;
+        }
+        if (!ok) {
+            if (threadIdx.x == 0) flags[rec] = (uint8_t)why;
+            __syncthreads();
+            continue;
+        }
+        double thr = med + 4.5 * 1.4826 * mad;
+        if (0.95 < thr) thr = 0.95;
+        __syncthreads();
+
+        // ---- threshold crossers in ascending order; each one is settled exactly
+        int total = 0;
+        bool overflow = false;
+        for (int base = 0; base < n && !overflow; base += PX_THREADS) {
+            const int i = base + threadIdx.x;
+            const bool cand = (i < n) && ((double)c[i] >= thr - DELTA);
+            if (threadIdx.x == 0) S.cnt = 0;
+            __syncthreads();
+            const unsigned long long bal = __ballot(cand);
+            if ((threadIdx.x & 63) == 0) { ((unsigned long long*)S.val)[threadIdx.x >> 6] = bal; if (bal) atomicOr((unsigned int*)&S.cnt, 1u); }
+            __syncthreads();
+            if (S.cnt == 0) continue;
+            unsigned long long mask[PX_THREADS / 64];
+            #pragma unroll
+            for (int w = 0; w < PX_THREADS / 64; ++w) mask[w] = ((unsigned long long*)S.val)[w];
+            __syncthreads();
+            for (int w = 0; w < PX_THREADS / 64 && !overflow; ++w) {
+                unsigned long long m = mask[w];
+                while (m) {
+                    const int bit = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int ci = base + 64 * w + bit;
+                    if (threadIdx.x == 0) S.cand_val = corr64_at(yr, ci, tpl);
+                    __syncthreads();
+                    const double cv = S.cand_val;
+                    __syncthreads();
+                    if (cv < thr) continue;                              // uniform
+                    int lo = ci - min_distance; if (lo < 0) lo = 0;
+                    int hi = ci + min_distance + 1; if (hi > n) hi = n;
+                    int bigger = 0, amb = 0;
+                    for (int j = lo + threadIdx.x; j < hi; j += PX_THREADS) {
+                        const double s32 = (double)c[j];
+                        if (s32 > cv + DELTA) bigger = 1;
+                        else if (s32 >= cv - DELTA && j != ci) {         // rival within reach: settle exactly
+                            ++amb;
+                            if (amb <= 4) bigger |= (corr64_at(yr, j, tpl) > cv);
+                        }
+                    }
+                    const int too_many = __syncthreads_or(amb > 4);
+                    if (too_many) { overflow = true; break; }
+                    if (__syncthreads_or(bigger) == 0) {
+                        if (threadIdx.x == 0 && total < ES_MAX_PEAKS) peaks[rec * ES_MAX_PEAKS + total] = ci;
+                        ++total;
+                    }
+                }
+            }
+        }
+        if (overflow) {
+            if (threadIdx.x == 0) flags[rec] = 4;                        // reason 4: too many rivals within DELTA
+            __syncthreads();
+            continue;
+        }
+
+        if (total == 0) {
+            // ---- fallback: five largest exact correlations (descending; equal values -> higher index)
+            const int kmax = n < 5 ? n : 5;
+            const float t5 = key_f32(px_select(S, n, n - kmax, [&](int i) { return f32_key(c[i]); }));
+            const double lo = (double)t5 - 2.0 * DELTA;
+            if (threadIdx.x == 0) S.cnt = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += PX_THREADS)
+                if ((double)c[i] >= lo) { const int slot = atomicAdd(&S.cnt, 1); if (slot < PX_CAP) S.list[slot] = i; }
+            __syncthreads();
+            const int nb = S.cnt;
+            if (nb > PX_CAP) {
+                if (threadIdx.x == 0) flags[rec] = 5;                    // reason 5: fallback list too long
+                __syncthreads();
+                continue;
+            }
+            if ((int)threadIdx.x < nb) S.val[threadIdx.x] = corr64_at(yr, S.list[threadIdx.x], tpl);
+            __syncthreads();
+            if ((int)threadIdx.x < nb) {
+                const double v = S.val[threadIdx.x]; const int idx = S.list[threadIdx.x];
+                int before = 0;                                          // how many sort ahead of me
+                for (int j = 0; j < nb; ++j) {
+                    const double vj = S.val[j]; const int ij = S.list[j];
+                    before += (vj > v) || (vj == v && ij > idx);
+                }
+                if (before < kmax) peaks[rec * ES_MAX_PEAKS + before] = idx;
+            }
+            if (threadIdx.x == 0) npeaks[rec] = kmax | (1 << 30);
+        } else if (threadIdx.x == 0) {
+            npeaks[rec] = total;
+        }
+        if (threadIdx.x == 0) { thr_out[rec] = thr; flags[rec] = 0; }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uint8_t* band, float* corr32, hipStream_t st)
+{
+    const int n_lags = T - (ES_PRE_L - 1);
+    const long long nseg = (n_lags + XC_SEG - 1) / XC_SEG;
+    long long blocks = (B * nseg + XC_WAVES - 1) / XC_WAVES;
+    const long long cap = (long long)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(es_xcorr32_kernel, dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32, (long long)B, T,
+                       band, ctx->d_tables, corr32);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}
+
+int es_launch_pick_exact(es_ctx* ctx, const float* corr32, const double* y, int64_t B, int T, const uint8_t* band,
+                         double* thr, int32_t* peaks, int32_t* npeaks, uint8_t* flags, hipStream_t st)
+{
+    if (T - (ES_PRE_L - 1) > PX_MAXN) { ctx->err = "es_pick_exact_batch: more than 4096 lags; use the float64 path"; return ES_EINVAL; }
+    long long blocks = B;
+    const long long cap = (long long)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(es_pick_exact_kernel, dim3((unsigned)blocks), dim3(PX_THREADS), 0, st, corr32, y, (long long)B, T,
+                       band, ctx->d_tables, thr, peaks, npeaks, flags);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}

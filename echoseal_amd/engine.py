@@ -44,6 +44,9 @@ class SyncResult:
     thr: torch.Tensor          # [B] float64
     peaks: torch.Tensor        # [B,32] int32
     npeaks: torch.Tensor       # [B] int32 (count; bit 30 = fallback branch)
+    corr32: torch.Tensor | None = None   # float32 screen (sync_fast only)
+    flags: torch.Tensor | None = None    # records redone in float64 (sync_fast only)
+    y32: torch.Tensor | None = None
 
 
 class RxEngine:
@@ -100,6 +103,54 @@ class RxEngine:
         nat.check(self._ctx, self._lib.es_bpf_batch(self._ctx, _ptr(frames), dt, B, T, _ptr(band), _ptr(y),
                                                     self._stream()), "es_bpf_batch")
         return y
+
+    def bpf2(self, frames: torch.Tensor, band: torch.Tensor):
+        """Band-pass with both outputs: y (float64) and y32 = (float)y."""
+        if frames.dim() != 2:
+            raise ValueError("frames must be [B, T]")
+        if frames.dtype == torch.int16:
+            dt = nat.ES_DTYPE_I16
+        elif frames.dtype == torch.float32:
+            dt = nat.ES_DTYPE_F32
+        else:
+            raise ValueError("frames must be float32 or int16")
+        frames = frames.contiguous()
+        B, T = frames.shape
+        y = torch.empty((B, T), dtype=torch.float64, device=self.device)
+        y32 = torch.empty((B, T), dtype=torch.float32, device=self.device)
+        nat.check(self._ctx, self._lib.es_bpf2_batch(self._ctx, _ptr(frames), dt, B, T, _ptr(band), _ptr(y), _ptr(y32),
+                                                     self._stream()), "es_bpf2_batch")
+        return y, y32
+
+    def xcorr32(self, y32: torch.Tensor, band: torch.Tensor) -> torch.Tensor:
+        B, T = y32.shape
+        corr = torch.empty((B, T - 62), dtype=torch.float32, device=self.device)
+        nat.check(self._ctx, self._lib.es_xcorr32_batch(self._ctx, _ptr(y32), B, T, _ptr(band), _ptr(corr),
+                                                        self._stream()), "es_xcorr32_batch")
+        return corr
+
+    def pick_exact(self, corr32: torch.Tensor, y: torch.Tensor, band: torch.Tensor):
+        """thr / peaks / npeaks identical to pick(xcorr(y)); also returns the per-record redo flags."""
+        B, T = y.shape
+        thr = torch.empty(B, dtype=torch.float64, device=self.device)
+        peaks = torch.full((B, nat.ES_MAX_PEAKS), -1, dtype=torch.int32, device=self.device)
+        npeaks = torch.empty(B, dtype=torch.int32, device=self.device)
+        flags = torch.empty(B, dtype=torch.uint8, device=self.device)
+        nat.check(self._ctx, self._lib.es_pick_exact_batch(self._ctx, _ptr(corr32), _ptr(y), B, T, _ptr(band), _ptr(thr),
+                                                           _ptr(peaks), _ptr(npeaks), _ptr(flags), self._stream()),
+                  "es_pick_exact_batch")
+        return thr, peaks, npeaks, flags
+
+    FAST_MAX_LAGS = 4096
+
+    def sync_fast(self, frames: torch.Tensor, band: torch.Tensor) -> SyncResult:
+        """Band-pass + float32 correlation screen + exact peak picking (results identical to sync())."""
+        y, y32 = self.bpf2(frames, band)
+        corr32 = self.xcorr32(y32, band)
+        thr, peaks, npeaks, flags = self.pick_exact(corr32, y, band)
+        res = SyncResult(y, None, thr, peaks, npeaks)
+        res.corr32, res.flags, res.y32 = corr32, flags, y32
+        return res
 
     def xcorr(self, y: torch.Tensor, band: torch.Tensor) -> torch.Tensor:
         B, T = y.shape
@@ -192,11 +243,20 @@ class RxEngine:
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.device)
-        y = self.bpf(frames, band)
-        corr = self.xcorr(y, band)
+        fast = (not keep_corr) and frames.shape[1] - 62 <= self.FAST_MAX_LAGS
+        if fast:      # float32 correlation screen + exact float64 fix-ups (identical thr / peaks)
+            y, y32 = self.bpf2(frames, band)
+            corr32 = self.xcorr32(y32, band)
+            corr = None
+        else:
+            y = self.bpf(frames, band)
+            corr = self.xcorr(y, band)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            thr, peaks, npeaks = self.pick(corr)
+            if fast:
+                thr, peaks, npeaks, _flags = self.pick_exact(corr32, y, band)
+            else:
+                thr, peaks, npeaks = self.pick(corr)
         llr = self.llr(y, band, pn_rows, start=start, variant=0)
         scl = self.scl(llr, list_size=list_size, skip_if_hard_ok=True)
         main.wait_stream(self._side)

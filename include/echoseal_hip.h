@@ -86,7 +86,24 @@ int es_xcorr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const uin
 int es_pick_batch(es_ctx* ctx, const double* corr_dev, int64_t B, int n_lags, double* thr_dev,
                   int32_t* peaks_dev, int32_t* npeaks_dev, void* stream);
 
-/* Convenience: the three calls above back to back (workspace owned by the context). */
+/* Float32 correlation screen + float64 exact fix-ups (same thr / peaks / npeaks as the float64
+ * calls above, bit for bit; see echoseal_amd/csrc/es_sync32.hip):
+ *   es_bpf2_batch        like es_bpf_batch, and also writes y32_dev [B][T] = (float)y
+ *                        (what _llr casts to anyway, rtwm/detector.py:323,329)
+ *   es_xcorr32_batch     corr32_dev [B][T-62] float32 from y32_dev: 4 860 B in + 4 612 B out per
+ *                        1215-sample record -- the HBM-graded kernel
+ *   es_pick_exact_batch  thr/peaks/npeaks from corr32 with float64 re-evaluation of every value
+ *                        near a decision; flags_dev [B] = 1 where the record had to be redone by the
+ *                        float64 kernels (done inside the call).  T - 62 <= 4096.                   */
+int es_bpf2_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
+                  const uint8_t* band_dev, double* y_dev, float* y32_dev, void* stream);
+int es_xcorr32_batch(es_ctx* ctx, const float* y32_dev, int64_t B, int T, const uint8_t* band_dev,
+                     float* corr32_dev, void* stream);
+int es_pick_exact_batch(es_ctx* ctx, const float* corr32_dev, const double* y_dev, int64_t B, int T,
+                        const uint8_t* band_dev, double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev,
+                        uint8_t* flags_dev, void* stream);
+
+/* Convenience: the three float64 calls above back to back (workspace owned by the context). */
 int es_sync_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
                   const uint8_t* band_dev, double* y_dev, double* corr_dev /* nullable */,
                   double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev, void* stream);
