@@ -118,21 +118,23 @@ def main() -> None:
     main = torch.cuda.current_stream(dev)
 
     def step(k=None):
-        # band-pass (y64 + y32) -> float32 correlation screen on the main stream, then two independent
-        # branches: exact peak picking (float64 fix-ups) on a side stream, (llr -> scl) on the main
-        # stream; joined before the step ends.  thr / peaks are bit-identical to the float64 path.
+        # band-pass (y64 + y32), then two independent branches that are joined before SCL so that the
+        # list decoder (one wave per SIMD at this batch size) gets the chip to itself:
+        #   main stream: float32 correlation screen -> exact peak picking (float64 fix-ups)
+        #   side stream: soft demodulation (LLR)
+        # thr / peaks are bit-identical to the float64 path.
         y, y32 = eng.bpf2(frames_d, band_d)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            llr = eng.llr(y, band_d, pn_d, variant=0)
         if k is not None:
             ev[k][0].record()
         corr32 = eng.xcorr32(y32, band_d)
         if k is not None:
             ev[k][1].record()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            thr, peaks, npeaks, flags = eng.pick_exact(corr32, y, band_d)
-        llr = eng.llr(y, band_d, pn_d, variant=0)
-        res = eng.scl(llr, list_size=L, skip_if_hard_ok=True)
+        thr, peaks, npeaks, flags = eng.pick_exact(corr32, y, band_d)
         main.wait_stream(side)
+        res = eng.scl(llr, list_size=L, skip_if_hard_ok=True)
         return res, peaks, npeaks
 
     for _ in range(a.warmup):

@@ -236,32 +236,29 @@ class RxEngine:
                      start: torch.Tensor | None = None, list_size: int = 8, keep_corr: bool = False):
         """sync + LLR(variant 0 at `start`, default 0) + SCL-L for every record.
 
-        After band-pass + correlation the chain forks: peak picking only needs `corr`, the
-        demodulator (frame start known) only `y`, so pick runs on a side HIP stream
-        while LLR + SCL run on the caller's stream (SCL leaves most of each CU's issue slots and
-        LDS free at small batch).  Both branches are joined before returning."""
+        After the band-pass the chain forks: correlation + peak picking and the demodulator (frame
+        start known) both only need `y`, so the LLR kernel runs on a side HIP stream beside them;
+        the branches are joined before the list decoder starts."""
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.device)
         fast = (not keep_corr) and frames.shape[1] - 62 <= self.FAST_MAX_LAGS
         if fast:      # float32 correlation screen + exact float64 fix-ups (identical thr / peaks)
             y, y32 = self.bpf2(frames, band)
-            corr32 = self.xcorr32(y32, band)
-            corr = None
         else:
             y = self.bpf(frames, band)
-            corr = self.xcorr(y, band)
         self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            if fast:
-                thr, peaks, npeaks, _flags = self.pick_exact(corr32, y, band)
-            else:
-                thr, peaks, npeaks = self.pick(corr)
-        llr = self.llr(y, band, pn_rows, start=start, variant=0)
+        with torch.cuda.stream(self._side):      # the demodulator only needs y: it runs beside sync
+            llr = self.llr(y, band, pn_rows, start=start, variant=0)
+        if fast:
+            corr = None
+            thr, peaks, npeaks, _flags = self.pick_exact(self.xcorr32(y32, band), y, band)
+        else:
+            corr = self.xcorr(y, band)
+            thr, peaks, npeaks = self.pick(corr)
+        main.wait_stream(self._side)             # join before SCL, which wants the chip to itself
+        llr.record_stream(main)
         scl = self.scl(llr, list_size=list_size, skip_if_hard_ok=True)
-        main.wait_stream(self._side)
-        for t in (thr, peaks, npeaks):
-            t.record_stream(main)
         return SyncResult(y, corr if keep_corr else None, thr, peaks, npeaks), llr, scl
 
 
