@@ -81,32 +81,34 @@ __global__ __launch_bounds__(64 * XC_WAVES) void es_xcorr32_kernel(const float* 
         wave_fence_lds();
 
         const float* w = s + lane * XC_R;
-        float num[XC_R], en[XC_R], sq_head[XC_R - 1];
+        float num[XC_R];
         #pragma unroll
         for (int r = 0; r < XC_R; ++r) num[r] = 0.0f;
-        float core = 0.0f, tail_run = 0.0f;
+        float core = 0.0f;                                   // squares of samples 18..62, shared by the chunk
+        // sample m meets lag r at tap k = m - r (0 <= k < 63)
         #define XC32_FMAS(m, v)                                                                 \
             _Pragma("unroll") for (int r = 0; r < XC_R; ++r) {                                  \
                 const int k = (m) - r;                                                          \
                 if (k >= 0 && k < ES_PRE_L) num[r] = __builtin_fmaf((v), tp[k], num[r]);        \
             }
         #pragma unroll
-        for (int m = 0; m < XC_R - 1; ++m) { const float v = w[m]; sq_head[m] = v * v; XC32_FMAS(m, v) }
-        en[XC_R - 1] = 0.0f;
-        #pragma unroll
-        for (int r = XC_R - 2; r >= 0; --r) en[r] = en[r + 1] + sq_head[r];
+        for (int m = 0; m < XC_R - 1; ++m) { const float v = w[m]; XC32_FMAS(m, v) }
         #pragma unroll
         for (int m = XC_R - 1; m < ES_PRE_L; ++m) { const float v = w[m]; core = __builtin_fmaf(v, v, core); XC32_FMAS(m, v) }
         #pragma unroll
-        for (int r = 0; r < XC_R; ++r) en[r] = en[r] + core;
-        #pragma unroll
-        for (int m = ES_PRE_L; m < ES_PRE_L - 1 + XC_R; ++m) {
-            const float v = w[m];
-            tail_run = __builtin_fmaf(v, v, tail_run);
-            en[m - (ES_PRE_L - 1)] = en[m - (ES_PRE_L - 1)] + tail_run;
-            XC32_FMAS(m, v)
-        }
+        for (int m = ES_PRE_L; m < ES_PRE_L - 1 + XC_R; ++m) { const float v = w[m]; XC32_FMAS(m, v) }
         #undef XC32_FMAS
+        // window energies: en[r] = (head_r + core) + tail_r, all terms >= 0 (well conditioned).  The 36
+        // edge samples are re-read from LDS here so that no energy state is live during the FMA loop.
+        float en[XC_R];
+        en[XC_R - 1] = 0.0f;
+        #pragma unroll
+        for (int r = XC_R - 2; r >= 0; --r) { const float v = w[r]; en[r] = __builtin_fmaf(v, v, en[r + 1]); }
+        #pragma unroll
+        for (int r = 0; r < XC_R; ++r) en[r] = en[r] + core;
+        float tail_run = 0.0f;
+        #pragma unroll
+        for (int r = 1; r < XC_R; ++r) { const float v = w[ES_PRE_L - 1 + r]; tail_run = __builtin_fmaf(v, v, tail_run); en[r] = en[r] + tail_run; }
         wave_fence_lds();
         #pragma unroll
         for (int r = 0; r < XC_R; ++r)
