@@ -99,3 +99,24 @@ def test_try_decode_frame_true_positive(engine):
         assert det._try_decode_frame(np.zeros(FRAME_LEN), 4) is False          # counter mismatch -> validator rejects
     finally:
         engine.llr = real_llr
+
+
+@pytest.mark.gpu
+def test_negative_cases_like_reference_suite(engine):
+    """Mirrors of the reference's negative tests (tests/test_false_positive.py, test_edge_cases.py,
+    test_detector.py wrong-key case): none of these may verify, none may raise."""
+    from echoseal_amd.embedder import WatermarkEmbedder
+    rng = np.random.default_rng(7)
+    det = WatermarkDetector(KEY, list_size=4, engine=engine)
+    assert det.verify(rng.normal(0, 0.1, 24_000).astype(np.float32), 48_000) is False        # white noise
+    assert det.verify(np.zeros(12_000, np.float32), 48_000) is False                          # digital silence
+    assert det.verify(0.5 * np.sin(2 * np.pi * 1000 * np.arange(12_000) / 48_000).astype(np.float32), 48_000) is False
+    tx = WatermarkEmbedder(b"\x11" * 32)
+    marked = tx.process(np.zeros(12_000, np.float32))
+    assert WatermarkDetector(b"\x22" * 32, list_size=4, engine=engine).verify(marked, 48_000) is False   # wrong key
+    assert det.session_nonce is None
+    # default list size (256) goes through the wide-list kernel
+    det256 = WatermarkDetector(KEY, engine=None)
+    assert det256._list_size == 256
+    frame = WatermarkEmbedder(KEY)._make_frame_chips()
+    assert det256._try_decode_frame(det256._bandpass(frame, (8000, 10000)), 0) in (True, False)
