@@ -10,10 +10,13 @@
 //     oracle/c/eso_dsp.c for the rationale -- kernel and oracle use the same definition);
 //   * every float32 sum (shift scores, mean, variance) reproduces NumPy's pairwise reduction:
 //     blocks of <=128 elements, 8 strided accumulators combined as ((0+1)+(2+3))+((4+5)+(6+7)),
-//     recursive halving above 128.  With <=1024 elements that tree has at most 8 leaves, which is
-//     exactly one wave: lane = leaf*8 + accumulator, combined with xor-shuffles 1,2,4 (inside a
-//     leaf) and 8,16,32 (across leaves).  Absent leaves contribute +0.0, which is exact;
-//   * medians are exact order statistics (wave-level radix select on the 32-bit keys).
+//     recursive halving above 128.  With <=1024 elements that tree has at most 16 leaves, which is
+//     exactly one wave: lane = leaf*4 + j owns accumulators j and j+4 of its leaf, combined with
+//     xor-shuffles 1,2 (inside a leaf) and 4,8,16,32 (across leaves).  Absent leaves contribute
+//     +0.0, which is exact;
+//   * medians are exact order statistics (block-wide 8-bit-digit radix select on the 32-bit keys);
+//   * the matched filter is register tiled: 6 consecutive outputs per thread slide over the
+//     samples they share (zero-padded in LDS, so the tap loop has no bounds).
 //
 // Build with -ffp-contract=off.
 #include "es_internal.h"
