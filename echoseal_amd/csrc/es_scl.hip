@@ -195,6 +195,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         // partial-sum blocks of depths 6..10 (sizes 16..1, block of S bits at bit S): one dword per path,
         // carried by value and moved together with ptrB at a sort; deeper words stay in LDS (betaL).
         uint32_t b0 = 0;
+        uint32_t frozen_word = 0;
         int cnt = 1;                      // live paths
         int info_idx = 0;
         if (lane < 32) { for (int s = 0; s < L; ++s) W.betaL[s][lane] = 0; }
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
 
 #ifdef ES_SCL_STAMPS
         unsigned long long t_big = 0, t_small = 0, t_dec_f = 0, t_dec_i = 0, t_beta = 0, t_misc = 0;
+        unsigned long long t_s1 = 0, t_s2 = 0, t_s3 = 0, t_s4 = 0;
         unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
         for (int i = 0; i < N; ++i) {
@@ -313,7 +315,8 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
             const double lam = ar[LGP];
 
             // --- decision
-            const bool frozen = (a.frozen.w[i >> 5] >> (i & 31)) & 1u;
+            if ((i & 31) == 0) frozen_word = a.frozen.w[i >> 5];      // one scalar load per 32 bits
+            const bool frozen = (frozen_word >> (i & 31)) & 1u;
             const double al = __builtin_fabs(lam);
             double lp;
             if (i & 1) {
@@ -336,14 +339,29 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 // (metrics staged in LDS; broadcast reads).  A v_readlane variant was measured slower.
                 const bool is_cand = (q < 2) && (path < cnt);
                 const int c = 2 * path + q;
+                ES_STAMP(t_s1);
                 if (is_cand) W.candm[c] = m;
                 wave_fence_lds();
                 const int nc = 2 * cnt;
+                // The 2L x 2L comparison matrix is split over the P lanes of a path: candidate b = q & 1
+                // is held by the P/2 lanes with that parity, each of which ranks it against a slice of
+                // the candidates; the partial ranks are then summed across those lanes.
+                constexpr int G = (P >= 2) ? P / 2 : 1;              // lanes sharing one candidate
+                constexpr int SPAN = (2 * L + G - 1) / G;            // candidates each of them compares against
+                const int cb = q & 1;
+                const double mc = __shfl(m, path * P + cb);          // metric of candidate 2*path + cb
+                const int cc_ = 2 * path + cb;
+                const int k0 = (q >> 1) * SPAN;
                 int rank = 0;
-                for (int k = 0; k < nc; ++k) {
-                    const double mk = W.candm[k];
-                    rank += ((mk < m) || (mk == m && k < c)) ? 1 : 0;
+                #pragma unroll
+                for (int u = 0; u < SPAN; ++u) {
+                    const int k = k0 + u;
+                    const double mk = W.candm[k < 2 * L ? k : 0];
+                    rank += ((k < nc) && ((mk < mc) || (mk == mc && k < cc_))) ? 1 : 0;
                 }
+                #pragma unroll
+                for (int o = 2; o < P; o <<= 1) rank += __shfl_xor(rank, o);
+                ES_STAMP(t_s2);
                 const int keep = nc < L ? nc : L;
                 // new path r continues the candidate of rank r; `src` = lane holding that candidate
                 // (parent * P + bit).  Dead paths mirror rank 0.
@@ -363,6 +381,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                     const int cc = W.sel[path < keep ? path : 0];
                     src = (cc >> 1) * P + (cc & 1);
                 }
+                ES_STAMP(t_s3);
                 const int parent = src / P;
                 bit = (uint32_t)(src % P);
                 const int myc = 2 * parent + (int)bit;
@@ -383,6 +402,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 cnt = keep;
                 ++info_idx;
                 wave_fence_lds();
+                ES_STAMP(t_s4);
             }
 
 #ifdef ES_SCL_STAMPS
@@ -467,6 +487,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         if (lane == 0 && a.dbg && f < 64) {
             unsigned long long* o = a.dbg + f * 8;
             o[0] = t_big; o[1] = t_small; o[2] = t_dec_f; o[3] = t_dec_i; o[4] = t_beta; o[5] = t_misc;
+            o[6] = t_s1; o[7] = t_s2; a.dbg[64 * 8 + 0] = t_s3; a.dbg[64 * 8 + 1] = t_s4;
         }
 #endif
     }
@@ -540,22 +561,22 @@ int launch_scl(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     a.scratch = ctx->d_scl_scratch;
 #ifdef ES_SCL_STAMPS
     static unsigned long long* dbg = nullptr;
-    if (!dbg) { ES_HIP_CHECK(ctx, hipMalloc(&dbg, 64 * 8 * 8)); }
-    ES_HIP_CHECK(ctx, hipMemset(dbg, 0, 64 * 8 * 8));
+    if (!dbg) { ES_HIP_CHECK(ctx, hipMalloc(&dbg, 65 * 8 * 8)); }
+    ES_HIP_CHECK(ctx, hipMemset(dbg, 0, 65 * 8 * 8));
     a.dbg = dbg;
 #endif
     hipLaunchKernelGGL(es_scl_kernel<L>, dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
 #ifdef ES_SCL_STAMPS
     {   // diagnostic build only: print the per-segment cycle shares of the first frames
-        unsigned long long h[64 * 8];
+        unsigned long long h[65 * 8];
         ES_HIP_CHECK(ctx, hipDeviceSynchronize());
         ES_HIP_CHECK(ctx, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
         const char* nm[6] = {"chain S>=16", "chain S<=8", "decide frozen", "decide info", "beta fold", "misc"};
         unsigned long long tot = 0; for (int k = 0; k < 6; ++k) tot += h[k];
         fprintf(stderr, "[scl stamps L=%d] frame0 total %llu cycles:", L, tot);
         for (int k = 0; k < 6; ++k) fprintf(stderr, " %s=%llu (%.1f%%)", nm[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n   info-bit split: pre(lp,pen)=%llu  candm+rank=%llu  select=%llu  shuffles+tb=%llu\n", h[6], h[7], h[64 * 8], h[64 * 8 + 1]);
     }
 #endif
     return ES_OK;
