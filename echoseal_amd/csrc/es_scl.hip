@@ -101,6 +101,42 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
     double r; __builtin_memcpy(&r, &u, 8); return r;
 }
 
+// lane l <-> lane l ^ S for a compile-time S, through DPP where the data-parallel primitives reach
+// (S = 1, 2: quad_perm; S = 4, 8: a row shift each way and a select); otherwise ds_bpermute.
+template <int S>
+__device__ __forceinline__ int xor_lanes_b32(int v, int lane)
+{
+    if constexpr (S == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else if constexpr (S == 4 || S == 8) {
+        const int up = __builtin_amdgcn_mov_dpp(v, 0x100 + S, 0xf, 0xf, true);             // row_shl:S  (lane l gets l+S)
+        const int dn = __builtin_amdgcn_mov_dpp(v, 0x110 + S, 0xf, 0xf, true);             // row_shr:S  (lane l gets l-S)
+        return (lane & S) ? dn : up;
+    } else return __shfl_xor(v, S);
+}
+template <int S>
+__device__ __forceinline__ double xor_lanes_f64(double x, int lane)
+{
+    uint64_t u; __builtin_memcpy(&u, &x, 8);
+    const uint32_t lo = (uint32_t)xor_lanes_b32<S>((int)(uint32_t)u, lane);
+    const uint32_t hi = (uint32_t)xor_lanes_b32<S>((int)(uint32_t)(u >> 32), lane);
+    u = ((uint64_t)hi << 32) | lo;
+    double r; __builtin_memcpy(&r, &u, 8); return r;
+}
+
+// S is a loop-unrolled constant at every call site, so the switch folds away.
+__device__ __forceinline__ double xor_lanes_f64_sw(double x, int S, int lane)
+{
+    switch (S) {
+        case 1: return xor_lanes_f64<1>(x, lane);
+        case 2: return xor_lanes_f64<2>(x, lane);
+        case 4: return xor_lanes_f64<4>(x, lane);
+        case 8: return xor_lanes_f64<8>(x, lane);
+        case 16: return xor_lanes_f64<16>(x, lane);
+        default: return xor_lanes_f64<32>(x, lane);
+    }
+}
+
 __device__ __forceinline__ uint8_t crc8_bytes(const uint8_t* b, int n)
 {
     uint32_t reg = 0;
@@ -283,7 +319,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                     const int S = P >> k;
                     const bool is_g = (i >> (NLEV - d)) & 1;
                     const double own = ar[k - 1];
-                    const double oth = __shfl_xor(own, S);
+                    const double oth = xor_lanes_f64_sw(own, S, lane);
                     const bool hi = (q & S) != 0;                    // this lane holds parent[j+S]
                     const double pa = hi ? oth : own;                // parent[j]
                     const double pb = hi ? own : oth;                // parent[j+S]
@@ -297,7 +333,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                         const bool pos1 = d1 > 0, pos2 = d2 > 0;
                         const double t1 = pos1 ? -d1 : d1, t2 = pos2 ? -d2 : d2;
                         const double mine = es_softplus_neg(hi ? t2 : t1, tab);
-                        const double theirs = __shfl_xor(mine, S);
+                        const double theirs = xor_lanes_f64_sw(mine, S, lane);
                         const double L1 = hi ? theirs : mine;         // log1p(exp(-|a-b|))
                         const double L2 = hi ? mine : theirs;         // log1p(exp(-|a+b|))
                         double r1 = (pos1 ? pa : pb) + L1;
