@@ -401,22 +401,12 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 const int keep = nc < L ? nc : L;
                 // new path r continues the candidate of rank r; `src` = lane holding that candidate
                 // (parent * P + bit).  Dead paths mirror rank 0.
-                int src;
-                if constexpr (L <= 0) {   // ballot-based inversion measured slower than the LDS scatter; kept for reference
-                    const int want = path < keep ? path : 0;
-                    src = 0;
-                    #pragma unroll
-                    for (int r = 0; r < L; ++r) {                     // inverse permutation through ballots
-                        const unsigned long long holders = __ballot(is_cand && rank == r);
-                        const int ln = (int)__builtin_ctzll(holders | (1ULL << 63));
-                        if (want == r) src = ln;
-                    }
-                } else {
-                    if (is_cand && rank < keep) W.sel[rank] = (uint8_t)c;
-                    wave_fence_lds();
-                    const int cc = W.sel[path < keep ? path : 0];
-                    src = (cc >> 1) * P + (cc & 1);
-                }
+                // (an inverse permutation through per-rank ballots and a v_readlane rank loop were both
+                // measured slower than this LDS scatter / gather)
+                if (is_cand && rank < keep) W.sel[rank] = (uint8_t)c;
+                wave_fence_lds();
+                const int cc = W.sel[path < keep ? path : 0];
+                const int src = (cc >> 1) * P + (cc & 1);
                 ES_STAMP(t_s3);
                 const int parent = src / P;
                 bit = (uint32_t)(src % P);

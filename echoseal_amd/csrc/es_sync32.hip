@@ -111,8 +111,12 @@ __global__ __launch_bounds__(64 * XC_WAVES) void es_xcorr32_kernel(const float* 
         for (int r = 1; r < XC_R; ++r) { const float v = w[ES_PRE_L - 1 + r]; tail_run = __builtin_fmaf(v, v, tail_run); en[r] = en[r] + tail_run; }
         wave_fence_lds();
         #pragma unroll
-        for (int r = 0; r < XC_R; ++r)
-            s[lane * XC_R + r] = num[r] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(en[r]) + 1e-12f);
+        for (int r = 0; r < XC_R; ++r) {
+            // an energy outside float32 range (|y| beyond ~1e18) would make the quotient silently wrong:
+            // emit NaN instead, which sends the record to the float64 kernels
+            const float q32 = num[r] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(en[r]) + 1e-12f);
+            s[lane * XC_R + r] = (en[r] < 3.0e38f) ? q32 : __builtin_nanf("");
+        }
         wave_fence_lds();
         const int nl = (n_lags - lag0 < XC_SEG) ? n_lags - lag0 : XC_SEG;
         float* cr = corr + rec * n_lags + lag0;

@@ -374,6 +374,8 @@ def _adversarial_records(rng, n, T):
     x[7, : T // 2] = x[7, T - T // 2:][: T // 2]                                         # repeated half
     x[8] = np.where(np.arange(T) % 2 == 0, 0.5, -0.5).astype(np.float32)                # Nyquist
     x[9] = 0.0; x[9, :63] = 1.0
+    x[10] *= 1e25                                                                      # float32 energy overflows
+    x[11, 100:200] *= 1e22
     return x
 
 
