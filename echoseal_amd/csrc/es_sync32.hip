@@ -25,6 +25,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void wave_fence_lds()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -33,92 +35,131 @@ __device__ __forceinline__ void wave_fence_lds()
 
 constexpr int XC_R = 19;                            // must equal es_sync.hip / oracle XC_CHUNK
 constexpr int XC_SEG = 64 * XC_R;
-constexpr int XC_NS = XC_SEG + ES_PRE_L - 1;
 constexpr int XC_WAVES = 4;
+constexpr int XC_MIN_WAVES = 4;                     // waves per SIMD the register allocation must allow
+constexpr int XC_R_SMALL = 5;                       // lags per lane of the small-batch screen kernel
 constexpr double DELTA = 3e-5;
 
 // ------------------------------------------------------------------------------------ xcorr32
-__global__ __launch_bounds__(64 * XC_WAVES) void es_xcorr32_kernel(const float* __restrict__ y, long long B,
-        int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
+// R = lags per lane.  R = 19 (one wave per frame-sized record) moves the fewest LDS bytes per FMA and is the
+// large-batch kernel; R = 5 spreads a record over four waves so that a 1 024-record launch still puts four
+// waves on every SIMD (latency-bound regime).  The screen value may differ in the last ulps between the two
+// (energy summation order); both satisfy the DELTA bound, and es_pick_exact_kernel is exact for either.
+// TC = record length known at compile time (0: use the argument).  With TC = 1 215 (a frame) every bounds
+// test of the load / store loops folds away.
+template <int R, int TC>
+__global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel(const float* __restrict__ y, long long B,
+        int T_arg, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
         float* __restrict__ corr)
 {
-    __shared__ float s_buf[XC_WAVES][XC_NS + 2];
+    const int T = TC ? TC : T_arg;
+    constexpr int SEG = 64 * R;
+    constexpr int NS = SEG + ES_PRE_L - 1;
+    __shared__ float s_buf[XC_WAVES][NS + 2];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: item, record, band are scalar
     float* s = s_buf[wv];
     const int n_lags = T - (ES_PRE_L - 1);
-    const int nseg = (n_lags + XC_SEG - 1) / XC_SEG;
+    const int nseg = (n_lags + SEG - 1) / SEG;
     const long long n_items = B * nseg;
     const long long stride = (long long)gridDim.x * XC_WAVES;
     // item -> (record, segment) with 32-bit arithmetic (the launcher keeps n_items < 2^31); nseg is 1
     // for frame-sized records, so the division disappears on the hot path
     auto rec_of = [&](unsigned it) { return nseg == 1 ? it : it / (unsigned)nseg; };
-    constexpr int NST = (XC_NS + 63) / 64;
+    constexpr int NST = (NS + 63) / 64;
     float stage[NST];                               // next record's samples, in flight while this one is computed
     int bi_next = 0;
     auto prefetch = [&](unsigned it) {
         const long long r = rec_of(it);
-        const int l0 = (nseg == 1) ? 0 : (int)(it - (unsigned)r * (unsigned)nseg) * XC_SEG;
+        const int l0 = (nseg == 1) ? 0 : (int)(it - (unsigned)r * (unsigned)nseg) * SEG;
         const float* src = y + r * T + l0;
-        const int ns = (T - l0 < XC_NS) ? T - l0 : XC_NS;
+        const int ns = (T - l0 < NS) ? T - l0 : NS;
         #pragma unroll
         for (int u = 0; u < NST; ++u) { const int i = lane + 64 * u; stage[u] = (i < ns) ? src[i] : 0.0f; }
         bi_next = (int)band[r];
     };
+    static_assert(R % 2 == 1, "R - 1 must be even (packed core energy)");
+    if (lane < 2) s[NS + lane] = 0.0f;               // the zero-tap partner of the last lag reads one past the samples
     unsigned item = (unsigned)(blockIdx.x * XC_WAVES + wv);
     if (item < (unsigned)n_items) prefetch(item);
     for (; item < (unsigned)n_items; item += (unsigned)stride) {
         const long long rec = rec_of(item);
-        const int lag0 = (nseg == 1) ? 0 : (int)(item - (unsigned)rec * (unsigned)nseg) * XC_SEG;
+        const int lag0 = (nseg == 1) ? 0 : (int)(item - (unsigned)rec * (unsigned)nseg) * SEG;
         const int bi = __builtin_amdgcn_readfirstlane(bi_next);
         #pragma unroll
-        for (int u = 0; u < NST; ++u) { const int i = lane + 64 * u; if (i < XC_NS) s[i] = stage[u]; }
+        for (int u = 0; u < NST; ++u) { const int i = lane + 64 * u; if (i < NS) s[i] = stage[u]; }
         if (item + (unsigned)stride < (unsigned)n_items) prefetch(item + (unsigned)stride);
         const float* tpg = tabs->tpl32[bi];
-        float tp[ES_PRE_L];                                  // loaded once per record, kept in SGPRs
+        f32x2 tp2[32];                                       // tap pairs (2i, 2i+1), tap 63 = 0: SGPR pairs for the record
         #pragma unroll
-        for (int k = 0; k < ES_PRE_L; ++k) tp[k] = tpg[k];
+        for (int i = 0; i < 32; ++i) { tp2[i].x = tpg[2 * i]; tp2[i].y = tpg[2 * i + 1]; }
         wave_fence_lds();
 
-        const float* w = s + lane * XC_R;
-        float num[XC_R];
+        // Packed FP32 (v_pk_fma_f32: two FMAs per lane per issue slot).  Each lag keeps two partial sums,
+        // .x over the even taps and .y over the odd taps; a pair of consecutive samples (one ds_read2_b32)
+        // meets the aligned tap pair (2i, 2i+1).  Even lags use the sample pairs that start at an even
+        // offset, odd lags the ones that start at an odd offset, so the tap pairs are the same 32 aligned
+        // SGPR pairs for every lag.  The 64th "tap" is zero; the sample it meets is the next lane's (or
+        // the zero pad), finite unless the record already holds a NaN/Inf, which flags the record anyway.
+        const float* w = s + lane * R;
+        f32x2 acc[R];
         #pragma unroll
-        for (int r = 0; r < XC_R; ++r) num[r] = 0.0f;
-        float core = 0.0f;                                   // squares of samples 18..62, shared by the chunk
-        // sample m meets lag r at tap k = m - r (0 <= k < 63)
-        #define XC32_FMAS(m, v)                                                                 \
-            _Pragma("unroll") for (int r = 0; r < XC_R; ++r) {                                  \
-                const int k = (m) - r;                                                          \
-                if (k >= 0 && k < ES_PRE_L) num[r] = __builtin_fmaf((v), tp[k], num[r]);        \
+        for (int r = 0; r < R; ++r) acc[r] = f32x2{0.0f, 0.0f};
+        f32x2 core2 = f32x2{0.0f, 0.0f};                     // squares of samples R-1 .. 61 (R-1 is even)
+        #define XC32_PK(par, jj, v2)                                                            \
+            _Pragma("unroll") for (int r = (par); r < R; r += 2) {                              \
+                const int k = 2 * (jj) + (par) - r;                                             \
+                if (k >= 0 && k <= ES_PRE_L - 1) acc[r] = __builtin_elementwise_fma((v2), tp2[k / 2], acc[r]); \
             }
         #pragma unroll
-        for (int m = 0; m < XC_R - 1; ++m) { const float v = w[m]; XC32_FMAS(m, v) }
+        for (int j = 0; j < (R - 1) / 2; ++j) {
+            const f32x2 e = f32x2{w[2 * j], w[2 * j + 1]}; XC32_PK(0, j, e)
+            const f32x2 o = f32x2{w[2 * j + 1], w[2 * j + 2]}; XC32_PK(1, j, o)
+        }
         #pragma unroll
-        for (int m = XC_R - 1; m < ES_PRE_L; ++m) { const float v = w[m]; core = __builtin_fmaf(v, v, core); XC32_FMAS(m, v) }
+        for (int j = (R - 1) / 2; j <= (ES_PRE_L - 2) / 2; ++j) {
+            const f32x2 e = f32x2{w[2 * j], w[2 * j + 1]}; core2 = __builtin_elementwise_fma(e, e, core2); XC32_PK(0, j, e)
+            const f32x2 o = f32x2{w[2 * j + 1], w[2 * j + 2]}; XC32_PK(1, j, o)
+        }
         #pragma unroll
-        for (int m = ES_PRE_L; m < ES_PRE_L - 1 + XC_R; ++m) { const float v = w[m]; XC32_FMAS(m, v) }
-        #undef XC32_FMAS
-        // window energies: en[r] = (head_r + core) + tail_r, all terms >= 0 (well conditioned).  The 36
-        // edge samples are re-read from LDS here so that no energy state is live during the FMA loop.
-        float en[XC_R];
-        en[XC_R - 1] = 0.0f;
+        for (int j = (ES_PRE_L - 2) / 2 + 1; j <= (R - 1 + ES_PRE_L - 1) / 2; ++j) {
+            const f32x2 e = f32x2{w[2 * j], w[2 * j + 1]}; XC32_PK(0, j, e)
+            const f32x2 o = f32x2{w[2 * j + 1], w[2 * j + 2]}; XC32_PK(1, j, o)
+        }
+        #undef XC32_PK
+        // window energies: en[r] = (head_r + core) + tail_r, all terms >= 0 (well conditioned).  The edge
+        // samples are re-read from LDS here so that no energy state is live during the FMA loop.
+        const float v62 = w[ES_PRE_L - 1];
+        const float core = __builtin_fmaf(v62, v62, core2.x + core2.y);
+        float en[R];
+        en[R - 1] = 0.0f;
         #pragma unroll
-        for (int r = XC_R - 2; r >= 0; --r) { const float v = w[r]; en[r] = __builtin_fmaf(v, v, en[r + 1]); }
+        for (int r = R - 2; r >= 0; --r) { const float v = w[r]; en[r] = __builtin_fmaf(v, v, en[r + 1]); }
         #pragma unroll
-        for (int r = 0; r < XC_R; ++r) en[r] = en[r] + core;
+        for (int r = 0; r < R; ++r) en[r] = en[r] + core;
         float tail_run = 0.0f;
         #pragma unroll
-        for (int r = 1; r < XC_R; ++r) { const float v = w[ES_PRE_L - 1 + r]; tail_run = __builtin_fmaf(v, v, tail_run); en[r] = en[r] + tail_run; }
-        wave_fence_lds();
+        for (int r = 1; r < R; ++r) { const float v = w[ES_PRE_L - 1 + r]; tail_run = __builtin_fmaf(v, v, tail_run); en[r] = en[r] + tail_run; }
+        float emin = en[0], emax = en[0];
         #pragma unroll
-        for (int r = 0; r < XC_R; ++r) {
-            // an energy outside float32 range (|y| beyond ~1e18) would make the quotient silently wrong:
-            // emit NaN instead, which sends the record to the float64 kernels
-            const float q32 = num[r] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(en[r]) + 1e-12f);
-            s[lane * XC_R + r] = (en[r] < 3.0e38f) ? q32 : __builtin_nanf("");
+        for (int r = 1; r < R; ++r) { emin = __builtin_fminf(emin, en[r]); emax = __builtin_fmaxf(emax, en[r]); }
+        wave_fence_lds();
+        // sqrt(en) >= 1e-6 makes the reference's "+ 1e-12" a relative 1e-6 effect (inside DELTA): one rsq
+        // instead of sqrt + rcp.  Near-silent windows, and energies outside float32 range (|y| beyond
+        // ~1e18, which would make the quotient silently wrong), take the careful form for the whole wave;
+        // an overflowed energy becomes NaN, which sends the record to the float64 kernels.
+        if (__builtin_amdgcn_ballot_w64(!(emin >= 1.0e-12f && emax < 3.0e38f)) == 0) {
+            #pragma unroll
+            for (int r = 0; r < R; ++r) s[lane * R + r] = (acc[r].x + acc[r].y) * __builtin_amdgcn_rsqf(en[r]);
+        } else {
+            #pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float q32 = (acc[r].x + acc[r].y) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(en[r]) + 1e-12f);
+                s[lane * R + r] = (en[r] < 3.0e38f) ? q32 : __builtin_nanf("");
+            }
         }
         wave_fence_lds();
-        const int nl = (n_lags - lag0 < XC_SEG) ? n_lags - lag0 : XC_SEG;
+        const int nl = (n_lags - lag0 < SEG) ? n_lags - lag0 : SEG;
         float* cr = corr + rec * n_lags + lag0;
         for (int i = lane; i < nl; i += 64) cr[i] = s[i];
         wave_fence_lds();
@@ -390,12 +431,22 @@ __global__ __launch_bounds__(PX_THREADS) void es_pick_exact_kernel(const float* 
 int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uint8_t* band, float* corr32, hipStream_t st)
 {
     const int n_lags = T - (ES_PRE_L - 1);
-    const long long nseg = (n_lags + XC_SEG - 1) / XC_SEG;
-    long long blocks = (B * nseg + XC_WAVES - 1) / XC_WAVES;
     const long long cap = (long long)ctx->num_cu * 16;
+    // fewer single-segment items than two waves per SIMD: split records four ways
+    const bool small = B * ((n_lags + XC_SEG - 1) / XC_SEG) < (long long)ctx->num_cu * 8;
+    const int seg = small ? 64 * XC_R_SMALL : XC_SEG;
+    const long long nseg = (n_lags + seg - 1) / seg;
+    long long blocks = (B * nseg + XC_WAVES - 1) / XC_WAVES;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(es_xcorr32_kernel, dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32, (long long)B, T,
-                       band, ctx->d_tables, corr32);
+    if (small)
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_SMALL, 0>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32);
+    else if (T == ES_FRAME_LEN)
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, ES_FRAME_LEN>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32);
+    else
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, 0>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }

@@ -1,6 +1,6 @@
 """Launch es_xcorr32_kernel on a C3-sized batch (for rocprofv3 --pmc / --stats)."""
-import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from echoseal_amd.engine import RxEngine
 eng = RxEngine(0); rng = np.random.default_rng(0)
 for B in (65536, 1024):
