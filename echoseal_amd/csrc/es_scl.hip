@@ -243,10 +243,25 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
         unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
         for (int i = 0; i < N; ++i) {
+            if ((i & 31) == 0) frozen_word = a.frozen.w[i >> 5];      // one scalar load per 32 bits
+            // --- all-frozen aligned block starting here?  (rate-0 node: no decisions inside it, so its
+            // leaf LLRs can be produced level by level with every lane busy instead of leaf by leaf)
+            int blk = 0;                                              // log2 of the block size, 0 = none
+            if ((i & 1) == 0 && P >= 2) {
+                const uint32_t fw = frozen_word >> (i & 31);
+                #pragma unroll
+                for (int t = 1; t <= 5; ++t) {
+                    const int S = 1 << t;
+                    const uint32_t m = (S == 32) ? 0xffffffffu : ((1u << S) - 1u);
+                    if (blk == t - 1 && (i & (S - 1)) == 0 && (fw & m) == m) blk = t;
+                }
+                if (blk == 5 && (i & 63) == 0 && a.frozen.w[(i >> 5) + 1] == 0xffffffffu) blk = 6;
+            }
+            const int d_stop = blk ? NLEV - blk : NLEV;               // deepest depth the leaf-serial chain computes
             // --- LLR chain: recompute the depths that changed since leaf i-1 (fastpolar.py:127-154)
             const int top = (i == 0) ? 1 : NLEV - __builtin_ctz((unsigned)i);
             // (a) depths above the register-resident part: slot storage in scratch / LDS
-            for (int d = top; d < RD; ++d) {
+            for (int d = top; d < RD && d <= d_stop; ++d) {
                 const int S = N >> d;
                 const bool is_g = (i >> (NLEV - d)) & 1;
                 const int ps = (d > 1) ? ptr_get(ptrA, d - 1) : 0;
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
 #endif
             }
             // (b) depth RD: one element per lane, straight from the slot of depth RD-1 into a register
-            if (RD >= top) {
+            if (RD >= top && RD <= d_stop) {
                 const int d = RD;
                 const bool is_g = (i >> (NLEV - d)) & 1;
                 double pa, pb;
@@ -314,8 +329,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
             #pragma unroll
             for (int k = 1; k <= LGP; ++k) {
                 const int d = RD + k;
-                if (d >= top) {
-                    constexpr int dummy = 0; (void)dummy;
+                if (d >= top && d <= d_stop) {
                     const int S = P >> k;
                     const bool is_g = (i >> (NLEV - d)) & 1;
                     const double own = ar[k - 1];
@@ -348,10 +362,88 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
 #ifdef ES_SCL_STAMPS
             ES_STAMP(t_small);
 #endif
+            uint32_t bit = 0;
+            if (blk) {
+                // ---------------- rate-0 block of S = 2^blk leaves (all bits 0: every g is b + a)
+                const int S = 1 << blk;
+                double* const X = &W.alphaS[path][S];                 // the node's S values (own slot), reused in place
+                if (S > P) {
+                    for (int h = S >> 1; h >= P; h >>= 1) {           // nodes of 2h values -> children of h values
+                        const int lh = 31 - __builtin_clz((unsigned)h);
+                        int idx = q;
+                        for (; idx + P < (S >> 1); idx += 2 * P) {    // two independent f chains in flight
+                            const int e0 = ((idx >> lh) << (lh + 1)) + (idx & (h - 1));
+                            const int e1 = (((idx + P) >> lh) << (lh + 1)) + ((idx + P) & (h - 1));
+                            const double a0 = X[e0], c0 = X[e0 + h], a1 = X[e1], c1 = X[e1 + h];
+                            const double o0 = es_polar_f(a0, c0, tab);
+                            const double o1 = es_polar_f(a1, c1, tab);
+                            X[e0] = o0; X[e0 + h] = es_polar_g(a0, c0, 0u);
+                            X[e1] = o1; X[e1 + h] = es_polar_g(a1, c1, 0u);
+                        }
+                        if (idx < (S >> 1)) {
+                            const int e0 = ((idx >> lh) << (lh + 1)) + (idx & (h - 1));
+                            const double a0 = X[e0], c0 = X[e0 + h];
+                            X[e0] = es_polar_f(a0, c0, tab); X[e0 + h] = es_polar_g(a0, c0, 0u);
+                        }
+                        wave_fence_lds();
+                    }
+                }
+                // sub-blocks of P values, one per lane: LGP more levels in registers (lane-split softplus as
+                // in (c)), then the P leaf penalties added to the metric in leaf order (fastpolar.py:281-286)
+                // (a block smaller than P sits in ar[LGP - blk], replicated, and starts further down)
+                const int k0 = (blk >= LGP) ? 0 : LGP - blk;
+                const int nsub = (S > P) ? S / P : 1;
+                const int nleaf = (S < P) ? S : P;
+                for (int sb = 0; sb < nsub; ++sb) {
+                    double x = ar[0];
+                    if (S > P) x = X[sb * P + q];
+                    #pragma unroll
+                    for (int k = 1; k <= LGP; ++k) if (k == k0) x = ar[k];
+                    double L2last = 0.0;
+                    #pragma unroll
+                    for (int k = 1; k <= LGP; ++k) {
+                        if (k <= k0) continue;
+                        const int h = P >> k;
+                        const double oth = xor_lanes_f64_sw(x, h, lane);
+                        const bool hi = (q & h) != 0;
+                        const double pa = hi ? oth : x, pb = hi ? x : oth;
+                        const double sum = pa + pb;
+                        const double d1 = pa - pb, d2 = 0.0 - sum;
+                        const bool pos1 = d1 > 0, pos2 = d2 > 0;
+                        const double t1 = pos1 ? -d1 : d1, t2 = pos2 ? -d2 : d2;
+                        const double mine = es_softplus_neg(hi ? t2 : t1, tab);
+                        const double theirs = xor_lanes_f64_sw(mine, h, lane);
+                        const double L1 = hi ? theirs : mine;
+                        const double L2 = hi ? mine : theirs;
+                        double r1 = (pos1 ? pa : pb) + L1;
+                        if (pa == pb) r1 = pa + ES_LOGE2;
+                        double r2 = (pos2 ? 0.0 : sum) + L2;
+                        if (0.0 == sum) r2 = 0.0 + ES_LOGE2;
+                        x = hi ? es_polar_g(pa, pb, 0u) : (r1 - r2);
+                        L2last = L2;
+                    }
+                    const double al = __builtin_fabs(x);
+                    // an odd leaf's penalty term is the log1p(exp(-|a+b|)) its even sibling's f just used
+                    const double lp = es_softplus_neg(-al, tab);
+                    double pen = (P >= 2 && (q & 1)) ? L2last : lp;
+                    if (x >= 0.0) pen = pen + al;
+                    #pragma unroll 8
+                    for (int k = 0; k < P; ++k) if (k < nleaf) metric = metric + __shfl(pen, path * P + k);
+                }
+                // partial sums of the block are all zero: clear the interior levels, then let the ordinary
+                // upward fold run from the block's last leaf
+                if (S >= 32) b0 = 0; else b0 &= ~((1u << S) - 1u);
+                for (int sl = 5; sl < blk; ++sl) {
+                    const int Wd = 1 << (sl - 5);
+                    for (int w = q; w < Wd; w += P) W.betaL[path][Wd + w] = 0;
+                    ptrB = ptr_set(ptrB, NLEV - sl, path);
+                }
+                wave_fence_lds();
+                i += S - 1;
+            } else {
             const double lam = ar[LGP];
 
             // --- decision
-            if ((i & 31) == 0) frozen_word = a.frozen.w[i >> 5];      // one scalar load per 32 bits
             const bool frozen = (frozen_word >> (i & 31)) & 1u;
             const double al = __builtin_fabs(lam);
             double lp;
@@ -361,7 +453,6 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 lp = es_softplus_neg(-al, tab);
             }
             const uint32_t pref = (lam >= 0.0) ? 1u : 0u;
-            uint32_t bit = 0;
             if (frozen) {                                             // fastpolar.py:281-286
                 double pen = lp;
                 if (pref != 0u) pen = lp + al;
@@ -434,6 +525,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
 #ifdef ES_SCL_STAMPS
             if (frozen) ES_STAMP(t_dec_f); else ES_STAMP(t_dec_i);
 #endif
+            }
             // --- partial sums: fold upward while the node is a right child (fastpolar.py:156-183)
             const int t = __builtin_ctz(~(unsigned)i);                // trailing ones of i
             if (t < NLEV) {
