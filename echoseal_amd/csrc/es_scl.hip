@@ -64,7 +64,12 @@ struct SclWave {
     uint8_t  outb[L][56];
 };
 
-template <int L> struct SclCfg { static constexpr int WPB = (L <= 8) ? 4 : (L == 16 ? 2 : 1); };
+template <int L> struct SclCfg {
+    static constexpr int WPB = (L <= 8) ? 4 : (L == 16 ? 2 : 1);
+    // LDS admits two blocks per CU; with four waves per block that is two waves per SIMD, which the register
+    // allocation must allow (256 VGPRs).  Longer lists run one wave per SIMD at most and may use more.
+    static constexpr int MIN_WAVES = (L <= 8) ? 2 : 1;
+};
 
 #ifdef ES_SCL_STAMPS
 #define ES_STAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
@@ -149,7 +154,7 @@ __device__ __forceinline__ uint8_t crc8_bytes(const uint8_t* b, int n)
 }
 
 template <int L>
-__global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
+__global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_scl_kernel(SclArgs a)
 {
     constexpr int WPB = SclCfg<L>::WPB;
     constexpr int P = 64 / L;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
             // --- all-frozen aligned block starting here?  (rate-0 node: no decisions inside it, so its
             // leaf LLRs can be produced level by level with every lane busy instead of leaf by leaf)
             int blk = 0;                                              // log2 of the block size, 0 = none
-            if ((i & 1) == 0 && P >= 2) {
+            if ((i & 1) == 0 && P >= 2 && i != 0) {       // (the first chain lives in the shared slot 0: leaf-serial there)
                 const uint32_t fw = frozen_word >> (i & 31);
                 #pragma unroll
                 for (int t = 1; t <= 5; ++t) {
@@ -269,8 +274,15 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 // parent block (depth d-1, 2S values) and destination block (depth d, S values)
                 const double* par_g = scr + ps * GSLOT + (N - 4 * S);          // depth d-1 in scratch: 0,512,768
                 const double* par_l = &W.alphaS[ps][2 * S];
-                double* dst_g = scr + path * GSLOT + (N - 2 * S);
-                double* dst_l = &W.alphaS[path][S];
+                // First chain (i == 0): every path is still a mirror of path 0, so the node is computed ONCE,
+                // by all 64 lanes, into slot 0, and every path points at it; a path's own slot takes over at
+                // the next recomputation of this depth, which all paths do together.
+                const bool first = (i == 0);
+                const int own = first ? 0 : path;
+                const int j0 = first ? lane : q;
+                const int jst = first ? 64 : P;
+                double* dst_g = scr + own * GSLOT + (N - 2 * S);
+                double* dst_l = &W.alphaS[own][S];
                 auto load_pair = [&](int j, double& pa, double& pb) {
                     if (d == 1) {
                         if (a.is_f64) { pa = llr64[j]; pb = llr64[j + S]; }
@@ -286,17 +298,17 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                         store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
                     }
                 } else {
-                    int j = q;
-                    for (; j + P < S; j += 2 * P) {            // two independent f chains in flight
-                        double a0, b0, a1, b1; load_pair(j, a0, b0); load_pair(j + P, a1, b1);
+                    int j = j0;
+                    for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
+                        double a0, b0, a1, b1; load_pair(j, a0, b0); load_pair(j + jst, a1, b1);
                         const double o0 = es_polar_f(a0, b0, tab);
                         const double o1 = es_polar_f(a1, b1, tab);
-                        store_out(j, o0); store_out(j + P, o1);
+                        store_out(j, o0); store_out(j + jst, o1);
                     }
                     if (j < S) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
                 }
                 if (d <= GDEPTH) wave_fence_global(); else wave_fence_lds();
-                ptrA = ptr_set(ptrA, d, path);
+                ptrA = ptr_set(ptrA, d, own);
 #ifdef ES_SCL_STAMPS
                 ES_STAMP(t_big);
 #endif
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB) void es_scl_kernel(SclArgs a)
                 }
                 wave_fence_lds();
                 i += S - 1;
+                ES_STAMP(t_misc);
             } else {
             const double lam = ar[LGP];
 
@@ -690,7 +703,7 @@ int launch_scl(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
         unsigned long long h[65 * 8];
         ES_HIP_CHECK(ctx, hipDeviceSynchronize());
         ES_HIP_CHECK(ctx, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
-        const char* nm[6] = {"chain S>=16", "chain S<=8", "decide frozen", "decide info", "beta fold", "misc"};
+        const char* nm[6] = {"chain S>=16", "chain S<=8", "decide frozen", "decide info", "beta fold", "rate-0 blocks + misc"};
         unsigned long long tot = 0; for (int k = 0; k < 6; ++k) tot += h[k];
         fprintf(stderr, "[scl stamps L=%d] frame0 total %llu cycles:", L, tot);
         for (int k = 0; k < 6; ++k) fprintf(stderr, " %s=%llu (%.1f%%)", nm[k], h[k], 100.0 * h[k] / (tot ? tot : 1));

@@ -1,6 +1,6 @@
 """Diagnostic: run the stamped SCL build (libechoseal_hip_diag.so) and a batch-size sweep."""
 import sys, time, os, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import echoseal_amd._native as nat
 if len(sys.argv) > 1 and sys.argv[1] == "diag":
     nat.LIB_PATH = os.path.join(os.path.dirname(nat.LIB_PATH), "libechoseal_hip_diag.so")
