@@ -36,6 +36,9 @@ __device__ __forceinline__ void wave_fence_lds()
 constexpr int XC_R = 19;                            // must equal es_sync.hip / oracle XC_CHUNK
 constexpr int XC_SEG = 64 * XC_R;
 constexpr int XC_WAVES = 4;
+#ifndef XC_GRID_PER_CU
+#define XC_GRID_PER_CU 16                            // blocks per CU the grid is capped at (grid-stride beyond)
+#endif
 constexpr int XC_MIN_WAVES = 4;                     // waves per SIMD the register allocation must allow
 constexpr int XC_R_SMALL = 5;                       // lags per lane of the small-batch screen kernel
 constexpr double DELTA = 3e-5;
@@ -81,8 +84,12 @@ __global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel
     static_assert(R % 2 == 1, "R - 1 must be even (packed core energy)");
     if (lane < 2) s[NS + lane] = 0.0f;               // the zero-tap partner of the last lag reads one past the samples
     unsigned item = (unsigned)(blockIdx.x * XC_WAVES + wv);
-    if (item < (unsigned)n_items) prefetch(item);
-    for (; item < (unsigned)n_items; item += (unsigned)stride) {
+    if (item >= (unsigned)n_items) return;
+    prefetch(item);
+    // The body is instantiated twice, once peeled in front of the loop: inside the loop the 19 stores of
+    // the previous record are then ALWAYS younger than the loads being waited for, so the compiler waits
+    // with a counted vmcnt and a wave never stalls on its own output stores.
+    auto body = [&](unsigned item) __attribute__((always_inline)) {
         const long long rec = rec_of(item);
         const int lag0 = (nseg == 1) ? 0 : (int)(item - (unsigned)rec * (unsigned)nseg) * SEG;
         const int bi = __builtin_amdgcn_readfirstlane(bi_next);
@@ -161,9 +168,14 @@ __global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel
         wave_fence_lds();
         const int nl = (n_lags - lag0 < SEG) ? n_lags - lag0 : SEG;
         float* cr = corr + rec * n_lags + lag0;
-        for (int i = lane; i < nl; i += 64) cr[i] = s[i];
+        // straight-line stores (no loop): the compiler then knows how many are outstanding and waits for the
+        // NEXT record's loads with a counted vmcnt instead of draining these stores first
+        #pragma unroll
+        for (int u = 0; u < R; ++u) { const int i = lane + 64 * u; if (i < nl) cr[i] = s[i]; }
         wave_fence_lds();
-    }
+    };
+    body(item);
+    for (item += (unsigned)stride; item < (unsigned)n_items; item += (unsigned)stride) body(item);
 }
 
 // ------------------------------------------------------------------------------------ exact value
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(PX_THREADS) void es_pick_exact_kernel(const float* 
 int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uint8_t* band, float* corr32, hipStream_t st)
 {
     const int n_lags = T - (ES_PRE_L - 1);
-    const long long cap = (long long)ctx->num_cu * 16;
+    const long long cap = (long long)ctx->num_cu * XC_GRID_PER_CU;
     // fewer single-segment items than two waves per SIMD: split records four ways
     const bool small = B * ((n_lags + XC_SEG - 1) / XC_SEG) < (long long)ctx->num_cu * 8;
     const int seg = small ? 64 * XC_R_SMALL : XC_SEG;

@@ -1,9 +1,12 @@
 """Mean launch time of the float32 correlation screen at small batch sizes (HIP events, back-to-back launches)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import echoseal_amd._native as nat
+if len(sys.argv) > 1:
+    nat.LIB_PATH = os.path.join(os.path.dirname(nat.LIB_PATH), sys.argv[1])
 from echoseal_amd.engine import RxEngine
 eng = RxEngine(0); rng = np.random.default_rng(0)
-for B in (256, 1024, 2048, 4096, 16384, 65536):
+for B in ((65536, 262144) if len(sys.argv) > 1 else (256, 1024, 2048, 4096, 16384, 65536)):
     x = torch.from_numpy(rng.normal(0, 0.3, (B, 1215)).astype(np.float32)).to(eng.device)
     band = torch.from_numpy(rng.integers(0, 4, B).astype(np.uint8)).to(eng.device)
     y, y32 = eng.bpf2(x, band)
