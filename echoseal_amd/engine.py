@@ -262,6 +262,81 @@ class RxEngine:
         return SyncResult(y, corr if keep_corr else None, thr, peaks, npeaks), llr, scl
 
 
+class DecodePipeline:
+    """Streaming form of `RxEngine.decode_batch`, several batches in flight.
+
+    The list decoder of a 1 024-frame batch keeps ONE wave on every SIMD and is bound by FP64 issue and
+    latency: a lone wave gets every other issue slot, so half of the vector unit idles.  Batches are
+    independent, so `submit` enqueues
+      * the front end (band-pass, float32 correlation screen + exact float64 peak picking; the LLR kernel on
+        a side stream next to sync, as in decode_batch) on one HIP stream, and
+      * the list decoder on one of `scl_streams` further streams, alternating, ordered after its front end
+        by an event.  Each of those streams decodes through its own context (own scratch slab), so two list
+        decoders can be resident at once: two waves per SIMD, the occupancy a 4 096-frame batch would have.
+    At most `depth` (= scl_streams) batches are in flight.  Results are complete after `wait(result)` / `synchronize()`;
+    values are those of decode_batch (same kernels, same order per batch)."""
+
+    def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2):
+        self.eng = eng
+        self.list_size = int(list_size)
+        dev = eng.device
+        # the short front-end kernels get dispatch priority over the long-running list decoders
+        self.front = torch.cuda.Stream(dev, priority=-1)
+        self.side = torch.cuda.Stream(dev, priority=-1)
+        self.backs = [torch.cuda.Stream(dev) for _ in range(max(1, int(scl_streams)))]
+        self.scl_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in self.backs[1:]]
+        # Batches in flight = list-decoder streams: the front end of batch k waits for batch k-2 to leave, so it
+        # runs while only ONE list decoder is resident (two of them fill every SIMD's register file and would
+        # starve the short front-end kernels of wave slots), and its own list decoder then starts beside the
+        # one still running.
+        self.depth = len(self.backs)
+        self._inflight: list = []            # `done` events of the most recent batches
+        self._k = 0
+
+    def submit(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *,
+               start: torch.Tensor | None = None, xcorr_events=None):
+        eng = self.eng
+        if frames.shape[1] - 62 > eng.FAST_MAX_LAGS:
+            raise ValueError("DecodePipeline serves frame-sized records (use RxEngine.decode_batch for long captures)")
+        self.front.wait_stream(torch.cuda.current_stream(eng.device))   # inputs were produced on the caller's stream
+        if len(self._inflight) >= self.depth:                           # at most `depth` batches in flight
+            self.front.wait_event(self._inflight.pop(0))
+        with torch.cuda.stream(self.front):
+            y, y32 = eng.bpf2(frames, band)
+            if xcorr_events is not None:
+                xcorr_events[0].record()
+            corr32 = eng.xcorr32(y32, band)
+            if xcorr_events is not None:
+                xcorr_events[1].record()
+            self.side.wait_stream(self.front)
+            with torch.cuda.stream(self.side):
+                llr = eng.llr(y, band, pn_rows, start=start, variant=0)
+            thr, peaks, npeaks, flags = eng.pick_exact(corr32, y, band)
+            self.front.wait_stream(self.side)
+            ready = torch.cuda.Event()
+            ready.record()
+        j = self._k % len(self.backs)
+        self._k += 1
+        back = self.backs[j]
+        back.wait_event(ready)
+        llr.record_stream(back)
+        with torch.cuda.stream(back):
+            scl = self.scl_engs[j].scl(llr, list_size=self.list_size, skip_if_hard_ok=True)
+            done = torch.cuda.Event()
+            done.record()
+        self._inflight.append(done)
+        return SyncResult(y, None, thr, peaks, npeaks, flags=flags), llr, scl, done
+
+    @staticmethod
+    def wait(result) -> None:
+        result[3].synchronize()
+
+    def synchronize(self) -> None:
+        self.front.synchronize(); self.side.synchronize()
+        for b in self.backs:
+            b.synchronize()
+
+
 def select_payload(scl: SclResult, row: int = 0, validator=None):
     """Host-side tail of PolarCode.decode (rtwm/fastpolar.py:268-276, 332-359) for one record:
     apply CRC / validator rules to the hard candidate and the metric-ordered list."""

@@ -447,3 +447,22 @@ def test_sync_fast_large_batch_property(engine):
     k = (ref.npeaks & 0xFFFF).clamp(max=32)
     mask = torch.arange(32, device=engine.device)[None, :] < k[:, None]
     assert torch.equal(ref.peaks[mask], fast.peaks[mask])
+
+
+def test_decode_pipeline_equals_decode_batch(engine):
+    """The two-deep streaming pipeline (front end of batch k+1 beside SCL of batch k) returns, for every
+    batch, exactly what decode_batch returns for it -- including when different batches are in flight."""
+    from echoseal_amd.engine import DecodePipeline
+    pipe = DecodePipeline(engine, list_size=8)
+    batches = [_workload(256, noise=n, seed=11 + k, ctr0=1000 * k) for k, n in enumerate((0.0, 0.05, 0.2, 0.0, 0.4))]
+    dev = [_dev(engine, *w) for w in batches]
+    out = [pipe.submit(f, b, p) for f, b, p in dev]           # all five enqueued back to back
+    pipe.synchronize()
+    for (f, b, p), (sy, llr, scl, done) in zip(dev, out):
+        rs, rl, rc = engine.decode_batch(f, b, p, list_size=8)
+        torch.cuda.synchronize()
+        assert torch.equal(sy.thr, rs.thr) and torch.equal(sy.peaks, rs.peaks) and torch.equal(sy.npeaks, rs.npeaks)
+        assert torch.equal(llr, rl)
+        assert torch.equal(scl.ncand, rc.ncand) and torch.equal(scl.hard_info, rc.hard_info)
+        assert torch.equal(scl.cand_info, rc.cand_info) and torch.equal(scl.cand_metric, rc.cand_metric)
+        assert torch.equal(scl.cand_ok, rc.cand_ok)
