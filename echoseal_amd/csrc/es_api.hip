@@ -292,4 +292,31 @@ int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8
     return es_launch_polar_encode(ctx, info_dev, B, code_dev, (hipStream_t)stream);
 }
 
+int es_aead_check_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* blobs_dev, int64_t n, int group,
+                        const uint32_t* ctr_dev, uint8_t* ok_dev, uint8_t* plain_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (n < 0 || group < 1) return fail(ctx, ES_EINVAL, "es_aead_check_batch: negative count or group < 1");
+    if (n == 0) return ES_OK;
+    if (!key32_host || !blobs_dev || !ctr_dev || !ok_dev) return fail(ctx, ES_EINVAL, "es_aead_check_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_aead_check(ctx, key32_host, blobs_dev, n, group, ctr_dev, ok_dev, plain_dev, (hipStream_t)stream);
+}
+
+int es_select_batch(es_ctx* ctx, const uint8_t* key32_host, const uint32_t* ctr_dev, int64_t B, int L,
+                    const uint8_t* hard_info_dev, const uint8_t* hard_ok_dev, const uint8_t* cand_info_dev,
+                    const double* cand_metric_dev, const uint8_t* cand_ok_dev, const int32_t* ncand_dev,
+                    uint8_t* payload_dev, int8_t* ok_dev, int32_t* which_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0 || L < 1) return fail(ctx, ES_EINVAL, "es_select_batch: negative batch or list size < 1");
+    if (B == 0) return ES_OK;
+    if (!hard_info_dev || !hard_ok_dev || !cand_info_dev || !cand_metric_dev || !cand_ok_dev || !ncand_dev ||
+        !payload_dev || !ok_dev || !which_dev) return fail(ctx, ES_EINVAL, "es_select_batch: null pointer");
+    if (key32_host && !ctr_dev) return fail(ctx, ES_EINVAL, "es_select_batch: a key needs the expected counters");
+    DeviceGuard g(ctx->device);
+    return es_launch_select(ctx, key32_host, ctr_dev, B, L, hard_info_dev, hard_ok_dev, cand_info_dev, cand_metric_dev,
+                            cand_ok_dev, ncand_dev, payload_dev, ok_dev, which_dev, (hipStream_t)stream);
+}
+
 }  // extern "C"

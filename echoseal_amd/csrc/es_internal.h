@@ -74,6 +74,11 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
                   const uint8_t* band, const uint8_t* pn, int variant, float* llr, int32_t* best_s,
                   float* score, hipStream_t st);
 
+int es_launch_aead_check(es_ctx* ctx, const uint8_t* key32, const uint8_t* blobs, int64_t n, int group, const uint32_t* ctr,
+                         uint8_t* ok, uint8_t* plain, hipStream_t st);
+int es_launch_select(es_ctx* ctx, const uint8_t* key32, const uint32_t* ctr, int64_t B, int L, const uint8_t* hard_info,
+                     const uint8_t* hard_ok, const uint8_t* cand_info, const double* cand_metric, const uint8_t* cand_ok,
+                     const int32_t* ncand, uint8_t* payload, int8_t* ok, int32_t* which, hipStream_t st);
 int es_launch_header(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t* start, const uint8_t* band,
                      const uint8_t* hdr_pn, uint8_t* ok, int32_t* val, float* score, int32_t* best_s, hipStream_t st);
 

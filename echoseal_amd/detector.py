@@ -215,6 +215,13 @@ class WatermarkDetector:
         l0 = eng.llr(y, bands, pn, variant=0)
         l1 = eng.llr(y, bands, pn, variant=1)
         res = eng.scl(torch.cat((l0, -l0, l1, -l1), dim=0), list_size=L, skip_if_hard_ok=False)
+        key = getattr(self._aead, "_key", None)
+        if key is not None:
+            # validator + candidate selection on the GPU (es_select_batch): same rules as select_payload with
+            # self._validator(ctr), without a Python callback per candidate
+            payload, ok, _which = eng.select(res, key32=key, ctrs=torch.tensor(ctrs * 4, dtype=torch.int64))
+            payload = payload.cpu().numpy(); ok = ok.cpu().numpy()
+            return [[payload[v * B + i].tobytes() if ok[v * B + i] == 1 else None for v in range(4)] for i in range(B)]
         out = []
         for i, ctr in enumerate(ctrs):
             val = self._validator(ctr)

@@ -231,6 +231,53 @@ class RxEngine:
                   "es_polar_encode_batch")
         return code
 
+    # ------------------------------------------------------------------ after the list decoder
+    def _ctr_dev(self, ctrs) -> torch.Tensor:
+        """Frame counters as the 32-bit words the kernels compare against (stored in an int32 tensor)."""
+        t = self._dev(ctrs, torch.int64) & 0xFFFFFFFF
+        return torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32).contiguous()
+
+    def aead_check(self, key32: bytes, blobs: torch.Tensor, ctrs: torch.Tensor, *, want_plain: bool = False):
+        """The detector's validator (rtwm/detector.py:168-176) on 55-byte blobs: [n,55] or [B,L,55] uint8 with
+        one expected counter per row / per B.  -> ok uint8 (same leading shape), optionally plaintext [...,27]."""
+        if len(key32) != 32:
+            raise ValueError("AEAD key must be 32 bytes")
+        if blobs.dtype != torch.uint8 or blobs.shape[-1] != 55 or blobs.dim() not in (2, 3):
+            raise ValueError("blobs must be uint8 [n,55] or [B,L,55]")
+        blobs = blobs.contiguous()
+        group = blobs.shape[1] if blobs.dim() == 3 else 1
+        n = blobs.numel() // 55
+        ctrs = self._ctr_dev(ctrs)
+        if ctrs.numel() * group != n:
+            raise ValueError("one expected counter per blob row (or per frame for [B,L,55]) is required")
+        ok = torch.empty(blobs.shape[:-1], dtype=torch.uint8, device=self.device)
+        plain = torch.empty(blobs.shape[:-1] + (27,), dtype=torch.uint8, device=self.device) if want_plain else None
+        nat.check(self._ctx, self._lib.es_aead_check_batch(self._ctx, bytes(key32), _ptr(blobs), n, group, _ptr(ctrs), _ptr(ok),
+                                                           _ptr(plain), self._stream()), "es_aead_check_batch")
+        return (ok, plain) if want_plain else ok
+
+    def select(self, scl: SclResult, *, key32: bytes | None = None, ctrs: torch.Tensor | None = None):
+        """Tail of PolarCode.decode (rtwm/fastpolar.py:268-276, 332-359) for every record of an SclResult, on the
+        GPU: -> (payload [B,55] uint8, ok [B] int8, which [B] int32).  key32=None is validator=None; with a key the
+        validator is `aead_check` against ctrs [B].  ok = -1 marks records whose list loop had been skipped."""
+        B, L = scl.cand_metric.shape
+        if key32 is not None:
+            if len(key32) != 32:
+                raise ValueError("AEAD key must be 32 bytes")
+            if ctrs is None:
+                raise ValueError("one expected counter per record is required with a key")
+            ctrs = self._ctr_dev(ctrs)
+            if ctrs.numel() != B:
+                raise ValueError("one expected counter per record is required with a key")
+        payload = torch.empty((B, 55), dtype=torch.uint8, device=self.device)
+        ok = torch.empty(B, dtype=torch.int8, device=self.device)
+        which = torch.empty(B, dtype=torch.int32, device=self.device)
+        nat.check(self._ctx, self._lib.es_select_batch(
+            self._ctx, None if key32 is None else bytes(key32), _ptr(ctrs) if key32 is not None else None, B, L,
+            _ptr(scl.hard_info), _ptr(scl.hard_ok), _ptr(scl.cand_info), _ptr(scl.cand_metric), _ptr(scl.cand_ok),
+            _ptr(scl.ncand), _ptr(payload), _ptr(ok), _ptr(which), self._stream()), "es_select_batch")
+        return payload, ok, which
+
     # ------------------------------------------------------------------ metric unit
     def decode_batch(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *,
                      start: torch.Tensor | None = None, list_size: int = 8, keep_corr: bool = False):

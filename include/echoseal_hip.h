@@ -151,6 +151,28 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
 int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8_t* code_dev,
                           void* stream);
 
+/* ---- the step after the list decoder ------------------------------------------------
+ * Payload validator: replaces the Python closure the reference passes to PolarCode.decode
+ * (rtwm/detector.py:168-176): SecureChannel.open (rtwm/crypto.py:39-43: blob = nonce 12 | ciphertext 27 | tag 16,
+ * ChaCha20-Poly1305 per RFC 8439, no AAD), plaintext starts with "ESAL", plaintext[4:8] big endian == counter.
+ * blobs_dev [n][55]; blob i is checked against ctr_dev[i / group] (group = L for a [B][L][55] candidate array,
+ * 1 for [B][55]); key32_host = the 32-byte AEAD key (host memory, passed by value to the kernel);
+ * ok_dev [n] 1/0; plain_dev nullable [n][27] (plaintext when the tag verifies, zeros otherwise).               */
+int es_aead_check_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* blobs_dev, int64_t n, int group,
+                        const uint32_t* ctr_dev, uint8_t* ok_dev, uint8_t* plain_dev, void* stream);
+
+/* Candidate selection: replaces the tail of PolarCode.decode (rtwm/fastpolar.py:268-276, 332-359) over the outputs
+ * of es_scl_batch: the hard candidate if its CRC holds and the validator accepts it; else the first list candidate
+ * (ascending metric) whose CRC holds and which the validator accepts (ok = 1); else the lowest-metric CRC-ok
+ * candidate; else the lowest-metric candidate (ok = 0).  key32_host == NULL means validator=None; otherwise the
+ * validator is the one of es_aead_check_batch with ctr_dev [B].  payload_dev [B][55]; ok_dev [B] int8 (1, 0, or
+ * -1 when ncand is 0 although the shortcut did not return: run es_scl_batch with skip_if_hard_ok = 0 when a
+ * validator is used); which_dev [B] int32 (-1 = hard candidate, else list index).                              */
+int es_select_batch(es_ctx* ctx, const uint8_t* key32_host, const uint32_t* ctr_dev, int64_t B, int L,
+                    const uint8_t* hard_info_dev, const uint8_t* hard_ok_dev, const uint8_t* cand_info_dev,
+                    const double* cand_metric_dev, const uint8_t* cand_ok_dev, const int32_t* ncand_dev,
+                    uint8_t* payload_dev, int8_t* ok_dev, int32_t* which_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,44 @@ def decode_header(frame, hdr_pn_bits, taps):
     out = np.zeros(3); diag = np.zeros(2)
     lib().eso_decode_header(_p(frame), int(frame.size), _p(pn), _p(h), int(h.size), _p(out), _p(diag))
     return bool(out[0]), int(out[1]), float(out[2]), int(diag[0])
+
+
+# ------------------------------------------------------------------------------- AEAD validator (section 8 f-2)
+def chacha20_block(key: bytes, counter: int, nonce: bytes) -> bytes:
+    out = np.zeros(64, np.uint8)
+    lib().eso_chacha20_block(_p(np.frombuffer(key, np.uint8)), ctypes.c_uint32(counter), _p(np.frombuffer(nonce, np.uint8)), _p(out))
+    return out.tobytes()
+
+def poly1305(otk: bytes, msg: bytes) -> bytes:
+    tag = np.zeros(16, np.uint8); m = np.frombuffer(msg, np.uint8) if msg else np.zeros(1, np.uint8)
+    lib().eso_poly1305(_p(np.frombuffer(otk, np.uint8)), _p(m), ctypes.c_size_t(len(msg)), _p(tag))
+    return tag.tobytes()
+
+def aead_open(key: bytes, nonce: bytes, aad: bytes, ct_and_tag: bytes):
+    """RFC 8439 open -> plaintext bytes, or None when the tag does not verify."""
+    ct, tag = ct_and_tag[:-16], ct_and_tag[-16:]
+    out = np.zeros(max(1, len(ct)), np.uint8)
+    a = np.frombuffer(aad, np.uint8) if aad else np.zeros(1, np.uint8)
+    c = np.frombuffer(ct, np.uint8) if ct else np.zeros(1, np.uint8)
+    ok = lib().eso_aead_open(_p(np.frombuffer(key, np.uint8)), _p(np.frombuffer(nonce, np.uint8)), _p(a), ctypes.c_size_t(len(aad)),
+                             _p(c), ctypes.c_size_t(len(ct)), _p(np.frombuffer(tag, np.uint8)), _p(out))
+    return out[:len(ct)].tobytes() if ok == 1 else None
+
+def validate_blobs(key: bytes, blobs, ctrs):
+    """Detector validator on [n,55] blobs with expected counters [n] -> (ok uint8[n], plain uint8[n,27])."""
+    blobs = _c(blobs, np.uint8).reshape(-1, 55); ctrs = _c(ctrs, np.uint32)
+    ok = np.zeros(len(blobs), np.uint8); plain = np.zeros((len(blobs), 27), np.uint8)
+    k = np.frombuffer(key, np.uint8)
+    for i in range(len(blobs)):
+        ok[i] = lib().eso_validate_blob(_p(k), _p(blobs[i]), ctypes.c_uint32(int(ctrs[i])), _p(plain[i]))
+    return ok, plain
+
+def select_validated(key, ctr, hard, hard_ok, cand, cand_ok, cand_metric, n):
+    """PolarCode.decode's candidate selection with the detector validator (key=None: validator None)
+    -> (payload bytes, ok flag or -1, which)."""
+    payload = np.zeros(55, np.uint8); which = ctypes.c_int(0)
+    kp = _p(np.frombuffer(key, np.uint8)) if key is not None else None
+    cand = _c(cand, np.uint8); cand_ok = _c(cand_ok, np.uint8); cand_metric = _c(cand_metric, np.float64)
+    ok = lib().eso_select_validated(kp, ctypes.c_uint32(int(ctr)), _p(_c(hard, np.uint8)), int(hard_ok), _p(cand), _p(cand_ok),
+                                    _p(cand_metric), int(n), _p(payload), ctypes.byref(which))
+    return payload.tobytes(), int(ok), int(which.value)

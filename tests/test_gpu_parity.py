@@ -466,3 +466,85 @@ def test_decode_pipeline_equals_decode_batch(engine):
         assert torch.equal(scl.ncand, rc.ncand) and torch.equal(scl.hard_info, rc.hard_info)
         assert torch.equal(scl.cand_info, rc.cand_info) and torch.equal(scl.cand_metric, rc.cand_metric)
         assert torch.equal(scl.cand_ok, rc.cand_ok)
+
+
+def _sealed_blobs(rng, n, key=KEY):
+    """n 55-byte blobs: sealed ESAL payloads, a third of them corrupted, some with a wrong magic / counter."""
+    from echoseal_amd.crypto import SecureChannel
+    sec = SecureChannel(key)
+    blobs = np.zeros((n, 55), np.uint8); ctrs = np.zeros(n, np.int64)
+    for i in range(n):
+        ctr = int(rng.integers(0, 2 ** 32))
+        pt = (b"ESAL" if i % 7 else b"ESAX") + ctr.to_bytes(4, "big") + rng.bytes(19)
+        b = bytearray(sec.seal(pt, nonce=rng.bytes(12)))
+        if i % 3 == 0:
+            b[int(rng.integers(0, 55))] ^= 1 << int(rng.integers(0, 8))
+        blobs[i] = np.frombuffer(bytes(b), np.uint8)
+        ctrs[i] = ctr if i % 5 else (ctr + 1) % 2 ** 32
+    return sec, blobs, ctrs
+
+
+def test_aead_check_kernel_vs_oracle(engine, oracle):
+    """the GPU validator equals the oracle (RFC 8439 restatement) bit for bit: verdicts and plaintexts,
+    flat [n,55] and grouped [B,L,55] layouts, counters above 2^31."""
+    rng = np.random.default_rng(21)
+    sec, blobs, ctrs = _sealed_blobs(rng, 4096)
+    key = sec._aead._key
+    want_ok, want_plain = oracle.validate_blobs(key, blobs, ctrs)
+    ok, plain = engine.aead_check(key, torch.from_numpy(blobs).to(engine.device), torch.from_numpy(ctrs), want_plain=True)
+    assert np.array_equal(ok.cpu().numpy(), want_ok) and np.array_equal(plain.cpu().numpy(), want_plain)
+    assert 0 < int(want_ok.sum()) < len(want_ok)
+    # grouped: 512 frames x 8 candidates, one counter per frame
+    g = blobs.reshape(512, 8, 55); gc = ctrs[::8].copy()
+    want_g, _ = oracle.validate_blobs(key, blobs, np.repeat(gc, 8))
+    okg = engine.aead_check(key, torch.from_numpy(g).to(engine.device), torch.from_numpy(gc))
+    assert np.array_equal(okg.cpu().numpy().reshape(-1), want_g)
+    with pytest.raises(ValueError):
+        engine.aead_check(key[:31], torch.from_numpy(blobs).to(engine.device), torch.from_numpy(ctrs))
+
+
+@pytest.mark.parametrize("L", [8, 64])
+def test_select_kernel_vs_oracle_and_host_rules(engine, oracle, L):
+    """Candidate selection on the GPU == oracle == the host replay of rtwm/fastpolar.py:268-276,332-359
+    (engine.select_payload), with validator None and with the AEAD validator.  The candidate lists are real list-decoder
+    outputs with sealed blobs planted at chosen positions so that every branch is taken."""
+    from echoseal_amd.engine import RxEngine, select_payload
+    eng = engine if L <= engine.list_size_max else RxEngine(0, list_size_max=L)
+    rng = np.random.default_rng(33 + L)
+    B = 96
+    llr = torch.from_numpy(np.clip(rng.normal(0, 3, (B, 1024)), -12, 12).astype(np.float32)).to(eng.device)
+    res = eng.scl(llr, list_size=L, skip_if_hard_ok=False)
+    from echoseal_amd.crypto import SecureChannel
+    sec = SecureChannel(KEY)
+    key = sec._aead._key
+    true_ctr = rng.integers(0, 2 ** 32, B)
+    blobs = np.stack([np.frombuffer(sec.seal(b"ESAL" + int(c).to_bytes(4, "big") + rng.bytes(19), nonce=rng.bytes(12)), np.uint8)
+                      for c in true_ctr])
+    ctrs = np.where(np.arange(B) % 12 >= 6, (true_ctr + 1) % 2 ** 32, true_ctr).astype(np.int64)   # second half-dozen: wrong counter
+    ci = res.cand_info.cpu().numpy().copy(); co = res.cand_ok.cpu().numpy().copy()
+    hi = res.hard_info.cpu().numpy().copy(); ho = res.hard_ok.cpu().numpy().copy()
+    for f in range(B):
+        mode = f % 6
+        if mode == 0:   hi[f] = blobs[f]; ho[f] = 1                      # valid hard candidate
+        elif mode == 1: ci[f, L // 2] = blobs[f]; co[f, L // 2] = 1; co[f, 1] = 1   # CRC-ok decoy first, valid one later
+        elif mode == 2: co[f, :] = 0                                     # nothing passes CRC
+        elif mode == 3: co[f, 3] = 1                                     # CRC-ok but never valid
+        elif mode == 4: ci[f, 0] = blobs[f]; co[f, 0] = 0                # valid blob whose CRC flag is off: must be ignored
+        else:           hi[f] = blobs[f]; ho[f] = 0; ci[f, L - 1] = blobs[f]; co[f, L - 1] = 1
+    res.cand_info.copy_(torch.from_numpy(ci)); res.cand_ok.copy_(torch.from_numpy(co))
+    res.hard_info.copy_(torch.from_numpy(hi)); res.hard_ok.copy_(torch.from_numpy(ho))
+    cm = res.cand_metric.cpu().numpy(); nc = res.ncand.cpu().numpy()
+    for use_key in (False, True):
+        payload, ok, which = eng.select(res, key32=key if use_key else None, ctrs=torch.from_numpy(ctrs) if use_key else None)
+        payload = payload.cpu().numpy(); ok = ok.cpu().numpy(); which = which.cpu().numpy()
+        seen = set()
+        for f in range(B):
+            wp, wok, ww = oracle.select_validated(key if use_key else None, ctrs[f], hi[f], ho[f], ci[f], co[f], cm[f], nc[f])
+            assert payload[f].tobytes() == wp and int(ok[f]) == wok and int(which[f]) == ww
+            def val(p, c=int(ctrs[f])):
+                pt = sec.open(p)
+                return pt.startswith(b"ESAL") and int.from_bytes(pt[4:8], "big") == c
+            hp, hok = select_payload(res, f, val if use_key else None)
+            assert hp == wp and bool(hok) == (wok == 1)
+            seen.add((wok, ww == -1))
+        assert len(seen) >= 3
