@@ -264,7 +264,12 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double rt = y - y * y * 0.5;
     res = tiny29 ? rt : res;
     res = tiny54 ? y : res;
-    *ok = exp_main && (tiny29 || hu != 0);
+    /* |t| < 2^-54 -- in practice t == 0, which is what two LLRs clipped to the same +-12 produce all the time:
+     * es_exp returns 1 + t = 1 and es_log1p(1) is the double nearest ln 2.  Answered here so that clipped
+     * inputs do not send the whole wavefront through the generic (branching) form. */
+    const int tzero = abstop < 0x3c9u;
+    res = tzero ? ES_LOGE2 : res;
+    *ok = tzero || (exp_main && (tiny29 || hu != 0));
     return res;
 }
 

@@ -65,3 +65,17 @@ def test_penalty_close_to_numpy(oracle):
         ref = np.where(pref != bit, pen + np.abs(l), pen)
         got = oracle.penalty_vec(l, bit)
         assert np.allclose(got, ref, rtol=5e-16, atol=0)
+
+
+def test_softplus_of_exact_zero(oracle):
+    """t == 0 (two LLRs clipped to the same value meet in f, or a leaf LLR is exactly 0) is answered by a constant
+    in the branch-free softplus: it must be libm's log1p(exp(0)) = log1p(1), for +0 and -0 and for |t| < 2^-54."""
+    import math
+    want = np.float64(math.log1p(math.exp(-0.0)))
+    for l in (0.0, -0.0, 2.0 ** -60, -(2.0 ** -60), 5e-324):
+        for bit in (0, 1):
+            got = oracle.penalty_vec(np.array([l]), bit)[0]
+            ref = want + abs(l) if (1 if l >= 0 else 0) != bit else want
+            assert _bits(np.array([got]))[0] == _bits(np.array([np.float64(ref)]))[0]
+    a = np.array([12.0, -12.0, 3.5, 0.0]); b = np.array([12.0, 12.0, -3.5, 0.0])
+    assert np.array_equal(_bits(oracle.polar_f_vec(a, b)), _bits(np.logaddexp(a, b) - np.logaddexp(0.0, a + b)))
