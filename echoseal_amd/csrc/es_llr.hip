@@ -86,6 +86,70 @@ __device__ __forceinline__ float wave_pairwise_sum(const PwPlan& p, int lane, F 
     return r;
 }
 
+// lane l <-> lane l ^ S through the data-parallel primitives (quad_perm for 1, 2; a row shift each way and a
+// select for 4, 8); 16 and 32 go through ds_bpermute.
+template <int S>
+__device__ __forceinline__ float xor_lanes_f32(float x, int lane)
+{
+    int v; __builtin_memcpy(&v, &x, 4);
+    int r;
+    if constexpr (S == 1) r = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);
+    else if constexpr (S == 2) r = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+    else if constexpr (S == 4 || S == 8) {
+        const int up = __builtin_amdgcn_mov_dpp(v, 0x100 + S, 0xf, 0xf, true);     // row_shl:S (lane l gets l+S)
+        const int dn = __builtin_amdgcn_mov_dpp(v, 0x110 + S, 0xf, 0xf, true);     // row_shr:S (lane l gets l-S)
+        r = (lane & S) ? dn : up;
+    } else r = __shfl_xor(v, S);
+    float o; __builtin_memcpy(&o, &r, 4); return o;
+}
+
+// The shift search evaluates the same pairwise tree hundreds of times per record on NON-NEGATIVE data (|win|), which
+// allows a latency-free form: every lane issues all the LDS reads of its leaf up front (absent elements read as
+// +0.0, and x + (+0.0) == x exactly for x >= +0), then adds in NumPy's order.  A leaf is at most 128 long (NumPy
+// only splits nodes longer than that): 16 strided steps of 8 and at most 7 trailing elements.
+struct PwLane { int st, full, ln; };
+__device__ __forceinline__ PwLane pw_lane(const PwPlan& p, int lane)
+{
+    const int leaf = lane >> 2;
+    int st = 0, ln = 0;
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) if (s == leaf) { st = p.start[s]; ln = p.len[s]; }
+    PwLane g; g.st = st; g.ln = ln; g.full = (ln >= 8) ? ln - (ln % 8) : 0;
+    return g;
+}
+__device__ __forceinline__ float wave_pairwise_sum_nonneg(const PwLane& g, int lane, const float* __restrict__ a)
+{
+    constexpr int NIT = 16;
+    const int jj = lane & 3;
+    float x0[NIT], x1[NIT], tl[7];
+    #pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const bool ok = 8 * k < g.full;
+        const int idx = ok ? g.st + 8 * k + jj : 0;
+        const float u = a[idx], v = a[idx + 4];
+        x0[k] = ok ? u : 0.0f; x1[k] = ok ? v : 0.0f;
+    }
+    #pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const bool ok = g.full + k < g.ln;
+        const float u = a[ok ? g.st + g.full + k : 0];
+        tl[k] = ok ? u : 0.0f;
+    }
+    float ra = x0[0], rb = x1[0];
+    #pragma unroll
+    for (int k = 1; k < NIT; ++k) { ra = ra + x0[k]; rb = rb + x1[k]; }
+    ra = ra + xor_lanes_f32<1>(ra, lane); rb = rb + xor_lanes_f32<1>(rb, lane);     // (r0+r1) , (r4+r5)
+    ra = ra + xor_lanes_f32<2>(ra, lane); rb = rb + xor_lanes_f32<2>(rb, lane);     // +(r2+r3), +(r6+r7)
+    float r = ra + rb;
+    #pragma unroll
+    for (int k = 0; k < 7; ++k) r = r + tl[k];
+    r = r + xor_lanes_f32<4>(r, lane);
+    r = r + xor_lanes_f32<8>(r, lane);
+    r = r + xor_lanes_f32<16>(r, lane);
+    r = r + xor_lanes_f32<32>(r, lane);
+    return r;
+}
+
 __device__ __forceinline__ uint32_t f32_key(float x)
 {
     uint32_t b; __builtin_memcpy(&b, &x, 4);
@@ -191,6 +255,7 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
     __shared__ int s_k;
     __shared__ float s_pn[NPAY];
     __shared__ float s_win[MAX_WIN];
+    __shared__ float s_abs[MAX_WIN];
     __shared__ float s_d[NPAY];
     __shared__ float s_score[4][2];
     __shared__ int   s_shift[4];
@@ -279,17 +344,21 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         }
         __syncthreads();
 
-        // ---- shift search (:366-379): score(s) = mean(|win[base+s+i] * pn[i]|, i >= guard)
+        // ---- shift search (:366-379): score(s) = mean(|win[base+s+i] * pn[i]|, i >= guard).  pn[i] is +-1, so
+        // |win * pn| == |win| exactly: the scores are NumPy pairwise sums over sliding windows of |win|, which is
+        // computed once; the PN symbols only enter at the despread.  (The sums themselves cannot slide: float32
+        // addition order is part of the result.)
+        for (int i = tid; i < nwin; i += LLR_THREADS) s_abs[i] = __builtin_fabsf(s_win[i]);
+        __syncthreads();
         PwPlan plan;
         pw_plan_build(plan, n - guard);
         const float cnt_f = (float)(n - guard);
+        const PwLane geo = pw_lane(plan, lane);
         float my_best = -1.0f, my_second = -1.0f; int my_s = 0;
         for (int s = -max_shift + wv; s <= max_shift; s += 4) {      // ascending within a wave
             const int i0 = base + s;
             if (i0 < 0 || i0 + n > nwin) continue;
-            const float* a = s_win + i0 + guard;
-            const float* b = s_pn + guard;
-            const float sum = wave_pairwise_sum(plan, lane, [&](int i) { return __builtin_fabsf(a[i] * b[i]); });
+            const float sum = wave_pairwise_sum_nonneg(geo, lane, s_abs + i0 + guard);
             const float score = sum / cnt_f;
             if (score > my_best) { my_second = my_best; my_best = score; my_s = s; }
             else if (score > my_second) my_second = score;
