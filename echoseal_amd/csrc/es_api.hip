@@ -50,6 +50,7 @@ es_ctx* es_create(int device, int list_size_max)
     /* every launch-time buffer the SCL kernel needs is allocated here, so es_scl_batch only
        enqueues work (hipGraph-capturable) */
     ctx->scl_scratch_bytes = es_scl_scratch_bytes(ctx);
+    if (es_scl_multi_scratch_bytes(ctx) > ctx->scl_scratch_bytes) ctx->scl_scratch_bytes = es_scl_multi_scratch_bytes(ctx);
     if (hipMalloc(&ctx->d_scl_scratch, ctx->scl_scratch_bytes) != hipSuccess) {
         g_create_err = "device allocation of the SCL scratch slab failed";
         ctx->d_scl_scratch = nullptr;
@@ -278,8 +279,28 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     if (list_size > 32)
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
+    if (list_size <= 8) {
+        // several frames per wave (es_scl_multi.hip) once the batch fills the chip with such waves: 16/L frames per
+        // wave, two waves per SIMD wanted
+        const long long waves = (B * list_size + 15) / 16;
+        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && waves >= (long long)ctx->num_cu * 8);
+        if (multi)
+            return es_launch_scl_multi(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
+                                       cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
+    }
     return es_launch_scl(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                          cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
+}
+
+int es_set_option(es_ctx* ctx, const char* name, int value)
+{
+    if (!ctx || !name) return ES_EINVAL;
+    if (std::strcmp(name, "scl_multi") == 0) {
+        if (value < -1 || value > 1) return fail(ctx, ES_EINVAL, "es_set_option: scl_multi takes -1 (auto), 0 or 1");
+        ctx->scl_multi = value;
+        return ES_OK;
+    }
+    return fail(ctx, ES_EINVAL, "es_set_option: unknown option");
 }
 
 int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8_t* code_dev, void* stream)

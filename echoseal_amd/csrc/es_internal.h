@@ -36,6 +36,8 @@ struct es_ctx {
     double* d_scl_scratch = nullptr;  size_t scl_scratch_bytes = 0;
     double* d_ws_corr = nullptr;      size_t ws_corr_bytes = 0;
     void*   d_wide_scratch = nullptr; size_t wide_scratch_bytes = 0; int wide_slots = 0;   /* list sizes 64..256 */
+    /* tuning (es_set_option) */
+    int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
 };
 
 #define ES_HIP_CHECK(ctx, expr)                                                         \
@@ -50,6 +52,10 @@ struct es_ctx {
 /* launchers implemented in the kernel translation units */
 size_t es_scl_scratch_bytes(const es_ctx* ctx);
 size_t es_scl_wide_scratch_bytes(const es_ctx* ctx, int* slots_out);
+size_t es_scl_multi_scratch_bytes(const es_ctx* ctx);
+int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
+                        uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
+                        uint8_t* cand_ok, int32_t* ncand, hipStream_t st);
 int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
                        uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
                        uint8_t* cand_ok, int32_t* ncand, hipStream_t st);

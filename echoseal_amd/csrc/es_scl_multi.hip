@@ -1,0 +1,505 @@
+// es_scl_multi.hip -- successive-cancellation LIST decoder for SHORT lists (L = 1, 2, 4, 8) with SEVERAL frames
+// per wavefront.  Same arithmetic, same bookkeeping and the same results as es_scl.hip; what changes is the
+// mapping to the hardware.
+//
+// Why: with one frame per wave (es_scl.hip) a path owns P = 64/L lanes, and the bottom of the LLR tree cannot
+// keep them busy: a leaf-level f() has two softplus terms per path, a leaf penalty one.  At L = 8 (P = 8) more
+// than half of all softplus evaluations run on 1 or 2 useful lanes out of 8, and L = 1 is no faster than L = 8.
+// Here a wave always carries 16 paths x 4 lanes: FR = 16/L frames of L paths each.  The top of the tree is as
+// efficient as before (every lane busy), the bottom wastes half as many lanes, and the wave's bookkeeping
+// (loop control, slot pointers, partial sums, sort latency) is shared by FR frames.  The frames of a wave
+// advance in lock step (the schedule depends on the leaf index only); a sort ranks a path against the
+// candidates of its own frame.
+//
+// LDS per wave is 17 KB (tree depths 5..7, partial sums, nibble-packed trace-back), four 2-wave blocks per CU:
+// two waves = 2*FR frames per SIMD.  Tree depths 1..4 live in the L2-resident scratch slab, depths 8..10 in
+// registers.  Reference lines as in es_scl.hip (rtwm/fastpolar.py:254-359).
+//
+// Build with -ffp-contract=off: every rounding step in es_math.h is explicit.
+#include "es_scl_common.h"
+
+namespace {
+
+constexpr int MP = 4;                              // lanes per path
+constexpr int MNP = 16;                            // paths per wave
+constexpr int MLGP = 2;                            // log2(MP)
+constexpr int MRD = NLEV - MLGP;                   // depths MRD..10 (sizes 4, 2, 1) live in registers
+constexpr int MGDEPTH = 4;                         // depths 1..4 live in global scratch
+constexpr int MGSLOT = 512 + 256 + 128 + 64;       // doubles per path slot in global scratch
+constexpr int MROW = 72;                           // depths 5..7 at [S, 2S), S = 32, 16, 8; + 8 pad
+constexpr int MWPB = 2;                            // waves per block
+
+struct MWave {
+    double   alphaS[MNP][MROW];
+    double   candm[2 * MNP];                       // frame fr: [2*L*fr, 2*L*(fr+1))
+    uint32_t betaL[MNP][32];                       // left-sibling partial sums, block of S bits at bit S
+    uint32_t curb[MNP][16];
+    uint32_t hardw[32];
+    uint8_t  tbn[KINFO][MNP / 2];                  // trace-back nibbles: (parent_local << 1) | bit, paths 2k | 2k+1 << 4
+    uint8_t  sel[MNP];
+    uint8_t  outb[MNP][56];
+};
+
+template <int L>
+__global__ __launch_bounds__(64 * MWPB, 2) void es_scl_multi_kernel(SclArgs a)
+{
+    constexpr int P = MP, LGP = MLGP, RD = MRD;
+    constexpr int FR = MNP / L;                    // frames per wave
+    constexpr int FL = 64 / FR;                    // lanes per frame
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8, "short lists only");
+    __shared__ __attribute__((aligned(16))) uint64_t s_exp[ES_EXP_TAB_WORDS];
+    __shared__ uint16_t s_dpos[KINFO];
+    __shared__ MWave s_wave[MWPB];
+
+    for (int i = threadIdx.x; i < ES_EXP_TAB_WORDS; i += blockDim.x) s_exp[i] = a.exp_tab[i];
+    for (int i = threadIdx.x; i < KINFO; i += blockDim.x) s_dpos[i] = a.data_pos[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int path = lane / P;                     // 0..15 within the wave
+    const int q = lane % P;
+    const int fr = path / L;                       // frame within the wave
+    const int pl = path % L;                       // path within the frame
+    const int fp0 = fr * L;                        // first path of the frame
+    MWave& W = s_wave[wv];
+    const long long wave_id = (long long)blockIdx.x * MWPB + wv;
+    const long long n_waves = (long long)gridDim.x * MWPB;
+    double* const scr = a.scratch + wave_id * (long long)(MNP * MGSLOT);
+    const uint64_t* const tab = s_exp;
+    const long long n_groups = (a.B + FR - 1) / FR;
+
+    for (long long g = wave_id; g < n_groups; g += n_waves) {
+        const long long f_raw = g * FR + fr;
+        const bool f_valid = f_raw < a.B;
+        const long long f = f_valid ? f_raw : a.B - 1;          // a missing frame mirrors the last one (never stored)
+        const float* llr32 = (const float*)a.llr + f * N;
+        const double* llr64 = (const double*)a.llr + f * N;
+
+        // ---------------- hard decision -> butterfly -> data bits -> CRC (fastpolar.py:260-268), frame by frame
+        uint32_t active_mask = 0;                              // wave-uniform: frames that go through the list loop
+        for (int fi = 0; fi < FR; ++fi) {
+            const long long ff = g * FR + fi;
+            if (ff >= a.B) break;
+            const float* l32 = (const float*)a.llr + ff * N;
+            const double* l64 = (const double*)a.llr + ff * N;
+            uint32_t word = 0;
+            for (int c = 0; c < 16; ++c) {
+                const double v = a.is_f64 ? l64[64 * c + lane] : (double)l32[64 * c + lane];
+                const unsigned long long m = __ballot(v > 0.0);
+                if (((lane & 31) >> 1) == c) word = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+            }
+            word ^= (word >> 1) & 0x55555555u;
+            word ^= (word >> 2) & 0x33333333u;
+            word ^= (word >> 4) & 0x0f0f0f0fu;
+            word ^= (word >> 8) & 0x00ff00ffu;
+            word ^= (word >> 16) & 0x0000ffffu;
+            #pragma unroll
+            for (int hw = 1; hw < 32; hw <<= 1) {
+                const uint32_t o = __shfl_xor(word, hw);
+                if (!((lane & 31) & hw)) word ^= o;
+            }
+            if (lane < 32) W.hardw[lane] = word;
+            wave_fence_lds();
+            if (lane < 56) {
+                uint32_t byte = 0;
+                #pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int pos = s_dpos[8 * lane + b];
+                    byte |= ((W.hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
+                }
+                W.outb[0][lane] = (uint8_t)byte;
+            }
+            wave_fence_lds();
+            int ok = 0;
+            if (lane == 0) ok = (crc8_bytes(W.outb[0], ES_INFO_BYTES) == W.outb[0][ES_INFO_BYTES]);
+            ok = __shfl(ok, 0);
+            if (lane < ES_INFO_BYTES) a.hard_info[ff * ES_INFO_BYTES + lane] = W.outb[0][lane];
+            if (lane == 0) a.hard_ok[ff] = (uint8_t)ok;
+            wave_fence_lds();
+            if (ok && a.skip_if_hard_ok) { if (lane == 0) a.ncand[ff] = 0; }
+            else active_mask |= 1u << fi;
+        }
+        if (active_mask == 0) continue;
+        const bool f_store = f_valid && ((active_mask >> fr) & 1u);
+
+        // ---------------- list decoding (fastpolar.py:278-330)
+        uint64_t ptrA = 0, ptrB = 0;
+        #pragma unroll
+        for (int d = 1; d <= NLEV; ++d) { ptrA = ptr_set(ptrA, d, fp0); ptrB = ptr_set(ptrB, d, fp0); }   // mirrors of the frame's path 0
+        double metric = 0.0;
+        double ar[LGP + 1];
+        #pragma unroll
+        for (int k = 0; k <= LGP; ++k) ar[k] = 0.0;
+        double sp_diff = 0.0, sp_sum = 0.0, lp_odd = 0.0;
+        uint32_t b0 = 0;
+        uint32_t frozen_word = 0;
+        int cnt = 1;                      // live paths per frame
+        int info_idx = 0;
+        if (lane < 32) { for (int s = 0; s < MNP; ++s) W.betaL[s][lane] = 0; }
+        wave_fence_lds();
+
+        for (int i = 0; i < N; ++i) {
+            if ((i & 31) == 0) frozen_word = a.frozen.w[i >> 5];
+            // --- all-frozen aligned block starting here (rate-0 node)?  log2 of its size, 0 = none
+            int blk = 0;
+            if ((i & 1) == 0 && i != 0) {
+                const uint32_t fw = frozen_word >> (i & 31);
+                #pragma unroll
+                for (int t = 1; t <= 5; ++t) {
+                    const int S = 1 << t;
+                    const uint32_t m = (S == 32) ? 0xffffffffu : ((1u << S) - 1u);
+                    if (blk == t - 1 && (i & (S - 1)) == 0 && (fw & m) == m) blk = t;
+                }
+                if (blk == 5 && (i & 63) == 0 && a.frozen.w[(i >> 5) + 1] == 0xffffffffu) blk = 6;
+            }
+            const int d_stop = blk ? NLEV - blk : NLEV;
+            // --- LLR chain: recompute the depths that changed since leaf i-1 (fastpolar.py:127-154)
+            const int top = (i == 0) ? 1 : NLEV - __builtin_ctz((unsigned)i);
+            // (a) depths above the register-resident part: slot storage in scratch / LDS
+            for (int d = top; d < RD && d <= d_stop; ++d) {
+                const int S = N >> d;
+                const bool is_g = (i >> (NLEV - d)) & 1;
+                const int ps = (d > 1) ? ptr_get(ptrA, d - 1) : 0;
+                const int bs = ptr_get(ptrB, d);
+                // First chain (i == 0): the paths of a frame are still copies of its path 0, so the node is computed
+                // once per frame, by the frame's FL lanes, into that path's slot.
+                const bool first = (i == 0);
+                const int own = first ? fp0 : path;
+                const int j0 = first ? (lane % FL) : q;
+                const int jst = first ? FL : P;
+                const double* par_g = scr + ps * MGSLOT + (N - 4 * S);         // depth d-1 in scratch: 0, 512, 768, 896
+                const double* par_l = &W.alphaS[ps][2 * S];
+                double* dst_g = scr + own * MGSLOT + (N - 2 * S);
+                double* dst_l = &W.alphaS[own][S];
+                auto load_pair = [&](int j, double& pa, double& pb) {
+                    if (d == 1) {
+                        if (a.is_f64) { pa = llr64[j]; pb = llr64[j + S]; }
+                        else { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }
+                    } else if (d - 1 <= MGDEPTH) { pa = par_g[j]; pb = par_g[j + S]; }
+                    else { pa = par_l[j]; pb = par_l[j + S]; }
+                };
+                auto store_out = [&](int j, double v) { if (d <= MGDEPTH) dst_g[j] = v; else dst_l[j] = v; };
+                if (is_g) {
+                    for (int j = q; j < S; j += P) {
+                        double pa, pb; load_pair(j, pa, pb);
+                        const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + j) >> 5];
+                        store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
+                    }
+                } else {
+                    int j = j0;
+                    for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
+                        double a0, c0, a1, c1; load_pair(j, a0, c0); load_pair(j + jst, a1, c1);
+                        const double o0 = es_polar_f(a0, c0, tab);
+                        const double o1 = es_polar_f(a1, c1, tab);
+                        store_out(j, o0); store_out(j + jst, o1);
+                    }
+                    if (j < S) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
+                }
+                if (d <= MGDEPTH) wave_fence_global(); else wave_fence_lds();
+                ptrA = ptr_set(ptrA, d, own);
+            }
+            // (b) depth RD: one element per lane, straight from the slot of depth RD-1 into a register
+            if (RD >= top && RD <= d_stop) {
+                const int d = RD;
+                const bool is_g = (i >> (NLEV - d)) & 1;
+                const double* par = &W.alphaS[ptr_get(ptrA, d - 1)][2 * P];
+                const double pa = par[q], pb = par[q + P];
+                if (is_g) ar[0] = es_polar_g(pa, pb, (b0 >> ((P + q) & 31)) & 1u);
+                else ar[0] = es_polar_f(pa, pb, tab);
+            }
+            // (c) depths RD+1..10: register to register, lane-split softplus (see es_scl.hip)
+            #pragma unroll
+            for (int k = 1; k <= LGP; ++k) {
+                const int d = RD + k;
+                if (d >= top && d <= d_stop) {
+                    const int S = P >> k;
+                    const bool is_g = (i >> (NLEV - d)) & 1;
+                    const double own = ar[k - 1];
+                    const double oth = xor_lanes_f64_sw(own, S, lane);
+                    const bool hi = (q & S) != 0;
+                    const double pa = hi ? oth : own;
+                    const double pb = hi ? own : oth;
+                    if (is_g) {
+                        const int j = q & (S - 1);
+                        ar[k] = es_polar_g(pa, pb, (b0 >> ((S + j) & 31)) & 1u);
+                    } else {
+                        const double sum = pa + pb;
+                        const double d1 = pa - pb, d2 = 0.0 - sum;
+                        const bool pos1 = d1 > 0, pos2 = d2 > 0;
+                        const double t1 = pos1 ? -d1 : d1, t2 = pos2 ? -d2 : d2;
+                        const double mine = es_softplus_neg(hi ? t2 : t1, tab);
+                        const double theirs = xor_lanes_f64_sw(mine, S, lane);
+                        const double L1 = hi ? theirs : mine;         // log1p(exp(-|a-b|))
+                        const double L2 = hi ? mine : theirs;         // log1p(exp(-|a+b|))
+                        double r1 = (pos1 ? pa : pb) + L1;
+                        if (pa == pb) r1 = pa + ES_LOGE2;
+                        double r2 = (pos2 ? 0.0 : sum) + L2;
+                        if (0.0 == sum) r2 = 0.0 + ES_LOGE2;
+                        ar[k] = r1 - r2;
+                        if (k == LGP) { sp_diff = L1; sp_sum = L2; }  // penalties of the odd sibling
+                    }
+                }
+            }
+
+            uint32_t bit = 0;
+            if (blk) {
+                // ---------------- rate-0 block of S = 2^blk leaves (all bits 0: every g is b + a); see es_scl.hip
+                const int S = 1 << blk;
+                if (S > P) {
+                    const int dn = NLEV - blk;                        // the node's depth: 4 (scratch) .. 7 (LDS)
+                    double* const Xg = scr + path * MGSLOT + (N - 2 * S);
+                    double* const Xl = &W.alphaS[path][S];
+                    const bool in_g = dn <= MGDEPTH;
+                    auto ld = [&](int e) { return in_g ? Xg[e] : Xl[e]; };
+                    auto st = [&](int e, double v) { if (in_g) Xg[e] = v; else Xl[e] = v; };
+                    for (int h = S >> 1; h >= P; h >>= 1) {           // nodes of 2h values -> children of h values
+                        const int lh = 31 - __builtin_clz((unsigned)h);
+                        int idx = q;
+                        for (; idx + P < (S >> 1); idx += 2 * P) {    // two independent f chains in flight
+                            const int e0 = ((idx >> lh) << (lh + 1)) + (idx & (h - 1));
+                            const int e1 = (((idx + P) >> lh) << (lh + 1)) + ((idx + P) & (h - 1));
+                            const double a0 = ld(e0), c0 = ld(e0 + h), a1 = ld(e1), c1 = ld(e1 + h);
+                            const double o0 = es_polar_f(a0, c0, tab);
+                            const double o1 = es_polar_f(a1, c1, tab);
+                            st(e0, o0); st(e0 + h, es_polar_g(a0, c0, 0u));
+                            st(e1, o1); st(e1 + h, es_polar_g(a1, c1, 0u));
+                        }
+                        if (idx < (S >> 1)) {
+                            const int e0 = ((idx >> lh) << (lh + 1)) + (idx & (h - 1));
+                            const double a0 = ld(e0), c0 = ld(e0 + h);
+                            st(e0, es_polar_f(a0, c0, tab)); st(e0 + h, es_polar_g(a0, c0, 0u));
+                        }
+                        if (in_g) wave_fence_global(); else wave_fence_lds();
+                    }
+                }
+                const int k0 = (blk >= LGP) ? 0 : LGP - blk;
+                const int nsub = (S > P) ? S / P : 1;
+                const int nleaf = (S < P) ? S : P;
+                for (int sb = 0; sb < nsub; ++sb) {
+                    double x = ar[0];
+                    if (S > P) x = (NLEV - blk <= MGDEPTH) ? scr[path * MGSLOT + (N - 2 * S) + sb * P + q] : W.alphaS[path][S + sb * P + q];
+                    #pragma unroll
+                    for (int k = 1; k <= LGP; ++k) if (k == k0) x = ar[k];
+                    double L2last = 0.0;
+                    #pragma unroll
+                    for (int k = 1; k <= LGP; ++k) {
+                        if (k <= k0) continue;
+                        const int h = P >> k;
+                        const double oth = xor_lanes_f64_sw(x, h, lane);
+                        const bool hi = (q & h) != 0;
+                        const double pa = hi ? oth : x, pb = hi ? x : oth;
+                        const double sum = pa + pb;
+                        const double d1 = pa - pb, d2 = 0.0 - sum;
+                        const bool pos1 = d1 > 0, pos2 = d2 > 0;
+                        const double t1 = pos1 ? -d1 : d1, t2 = pos2 ? -d2 : d2;
+                        const double mine = es_softplus_neg(hi ? t2 : t1, tab);
+                        const double theirs = xor_lanes_f64_sw(mine, h, lane);
+                        const double L1 = hi ? theirs : mine;
+                        const double L2 = hi ? mine : theirs;
+                        double r1 = (pos1 ? pa : pb) + L1;
+                        if (pa == pb) r1 = pa + ES_LOGE2;
+                        double r2 = (pos2 ? 0.0 : sum) + L2;
+                        if (0.0 == sum) r2 = 0.0 + ES_LOGE2;
+                        x = hi ? es_polar_g(pa, pb, 0u) : (r1 - r2);
+                        L2last = L2;
+                    }
+                    const double al = __builtin_fabs(x);
+                    const double lp = es_softplus_neg(-al, tab);
+                    double pen = (q & 1) ? L2last : lp;
+                    if (x >= 0.0) pen = pen + al;
+                    #pragma unroll
+                    for (int k = 0; k < P; ++k) if (k < nleaf) metric = metric + __shfl(pen, path * P + k);
+                }
+                if (S >= 32) b0 = 0; else b0 &= ~((1u << S) - 1u);
+                for (int sl = 5; sl < blk; ++sl) {
+                    const int Wd = 1 << (sl - 5);
+                    for (int w = q; w < Wd; w += P) W.betaL[path][Wd + w] = 0;
+                    ptrB = ptr_set(ptrB, NLEV - sl, path);
+                }
+                wave_fence_lds();
+                i += S - 1;
+            } else {
+            const double lam = ar[LGP];
+
+            // --- decision
+            const bool frozen = (frozen_word >> (i & 31)) & 1u;
+            const double al = __builtin_fabs(lam);
+            double lp;
+            if (i & 1) lp = lp_odd;                                  // set when the even sibling was decided
+            else lp = es_softplus_neg(-al, tab);
+            const uint32_t pref = (lam >= 0.0) ? 1u : 0u;
+            if (frozen) {                                             // fastpolar.py:281-286
+                double pen = lp;
+                if (pref != 0u) pen = lp + al;
+                metric = metric + pen;
+                lp_odd = sp_sum;                                      // sibling g = b + a when this bit is 0
+            } else {                                                  // fastpolar.py:288-330
+                double pen = lp;
+                if ((uint32_t)q != pref) pen = lp + al;
+                const double m = metric + pen;
+                // stable rank of candidate 2*pl + q among the 2*cnt live candidates of the frame
+                const bool is_cand = (q < 2) && (pl < cnt);
+                const int cl = 2 * pl + q;
+                if (is_cand) W.candm[2 * fp0 + cl] = m;
+                wave_fence_lds();
+                const int nc = 2 * cnt;
+                constexpr int G = P / 2;                             // lanes sharing one candidate
+                constexpr int SPAN = (2 * L + G - 1) / G;            // candidates each of them compares against
+                const int cb = q & 1;
+                const double mc = __shfl(m, path * P + cb);          // metric of candidate 2*pl + cb
+                const int cc_ = 2 * pl + cb;
+                const int kk0 = (q >> 1) * SPAN;
+                int rank = 0;
+                #pragma unroll
+                for (int u = 0; u < SPAN; ++u) {
+                    const int k = kk0 + u;
+                    const double mk = W.candm[2 * fp0 + (k < 2 * L ? k : 0)];
+                    rank += ((k < nc) && ((mk < mc) || (mk == mc && k < cc_))) ? 1 : 0;
+                }
+                rank += __shfl_xor(rank, 2);
+                const int keep = nc < L ? nc : L;
+                if (is_cand && rank < keep) W.sel[fp0 + rank] = (uint8_t)cl;
+                wave_fence_lds();
+                const int cc = W.sel[fp0 + (pl < keep ? pl : 0)];
+                const int src = (fp0 + (cc >> 1)) * P + (cc & 1);
+                const int parent = src / P;                          // path index within the wave
+                bit = (uint32_t)(cc & 1);
+                metric = __shfl(m, src);
+                ptrA = __shfl(ptrA, parent * P);
+                ptrB = __shfl((ptrB & 0xffffffffULL) | ((uint64_t)b0 << 32), parent * P);
+                b0 = (uint32_t)(ptrB >> 32);
+                ptrB &= 0xffffffffULL;
+                #pragma unroll
+                for (int k = 0; k <= LGP; ++k)
+                    if (((i + 1) & ((1 << (LGP - k)) - 1)) != 0) ar[k] = __shfl(ar[k], parent * P + q);
+                if (!(i & 1)) lp_odd = __shfl((q & 1) ? sp_diff : sp_sum, src);
+                // trace-back nibble (parent within the frame, bit); paths 2k and 2k+1 share a byte
+                const uint32_t nib = ((uint32_t)(cc >> 1) << 1) | bit;
+                const uint32_t nib_hi = (uint32_t)__shfl((int)nib, lane + P);
+                if (q == 0 && !(path & 1)) W.tbn[info_idx][path >> 1] = (uint8_t)(nib | (nib_hi << 4));
+                cnt = keep;
+                ++info_idx;
+                wave_fence_lds();
+            }
+            }
+            // --- partial sums: fold upward while the node is a right child (fastpolar.py:156-183)
+            const int t = __builtin_ctz(~(unsigned)i);                // trailing ones of i
+            if (t < NLEV) {
+                uint32_t cur = bit;
+                const int t5 = t < 5 ? t : 5;
+                for (int s = 0; s < t5; ++s) {
+                    const int S = 1 << s;
+                    const uint32_t left = (b0 >> S) & ((1u << S) - 1u);
+                    cur = (left ^ cur) | (cur << S);
+                }
+                if (t <= 5) {
+                    if (t < 5) {
+                        const int Sp = 1 << t;
+                        const uint32_t mask = ((1u << Sp) - 1u) << Sp;
+                        b0 = (b0 & ~mask) | (cur << Sp);
+                    } else if (q == 0) {
+                        W.betaL[path][1] = cur;
+                    }
+                } else {
+                    if (q == 0) W.curb[path][0] = cur;
+                    wave_fence_lds();
+                    for (int s = 5; s < t; ++s) {
+                        const int Wd = 1 << (s - 5);                  // words in the current block
+                        const int bs = ptr_get(ptrB, NLEV - s);
+                        for (int w = q; w < Wd; w += P) {
+                            const uint32_t c0 = W.curb[path][w];
+                            const uint32_t lf = W.betaL[bs][Wd + w];
+                            W.curb[path][Wd + w] = c0;
+                            W.curb[path][w] = c0 ^ lf;
+                        }
+                        wave_fence_lds();
+                    }
+                    const int Wp = 1 << (t - 5);
+                    for (int w = q; w < Wp; w += P) W.betaL[path][Wp + w] = W.curb[path][w];
+                }
+                if (t >= 5) {                                         // blocks of 32+ bits live in LDS slots
+                    ptrB = ptr_set(ptrB, NLEV - t, path);
+                    wave_fence_lds();
+                }
+            }
+        }
+
+        // ---------------- final ordering (fastpolar.py:335), trace-back, CRC -- per frame
+        if (q == 0) W.candm[path] = metric;
+        wave_fence_lds();
+        int rank = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const double mk = W.candm[fp0 + k];
+            rank += ((mk < metric) || (mk == metric && k < pl)) ? 1 : 0;
+        }
+        if (q == 0 && pl < cnt) {
+            int cur = pl;
+            uint32_t acc = 0;
+            for (int tt = KINFO - 1; tt >= 0; --tt) {
+                const int gp = fp0 + cur;
+                const uint32_t c = (W.tbn[tt][gp >> 1] >> (4 * (gp & 1))) & 15u;
+                acc |= (c & 1u) << (7 - (tt & 7));
+                cur = (int)(c >> 1);
+                if ((tt & 7) == 0) { W.outb[path][tt >> 3] = (uint8_t)acc; acc = 0; }
+            }
+            if (f_store) {
+                const int ok = crc8_bytes(W.outb[path], ES_INFO_BYTES) == W.outb[path][ES_INFO_BYTES];
+                a.cand_metric[f * L + rank] = metric;
+                a.cand_ok[f * L + rank] = (uint8_t)ok;
+            }
+        }
+        wave_fence_lds();
+        if (pl < cnt && f_store) {
+            for (int k = q; k < ES_INFO_BYTES; k += P)
+                a.cand_info[(f * L + rank) * ES_INFO_BYTES + k] = W.outb[path][k];
+        }
+        if (q == 0 && pl == 0 && f_store) a.ncand[f] = cnt;
+        wave_fence_lds();
+    }
+}
+
+template <int L>
+int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
+{
+    constexpr int FR = MNP / L;
+    const long long groups = (B + FR - 1) / FR;
+    long long blocks = (groups + MWPB - 1) / MWPB;
+    const long long max_blocks = (long long)ctx->num_cu * 4;    // LDS admits four blocks per CU
+    if (blocks > max_blocks) blocks = max_blocks;
+    if ((size_t)blocks * MWPB * MNP * MGSLOT * sizeof(double) > ctx->scl_scratch_bytes) {
+        ctx->err = "es_scl_batch: scratch slab too small for the multi-frame kernel"; return ES_ENOMEM;
+    }
+    SclArgs a = a0;
+    a.scratch = ctx->d_scl_scratch;
+    hipLaunchKernelGGL(es_scl_multi_kernel<L>, dim3((unsigned)blocks), dim3(64 * MWPB), 0, st, a);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}
+
+}  // namespace
+
+size_t es_scl_multi_scratch_bytes(const es_ctx* ctx)
+{
+    return (size_t)ctx->num_cu * 4 * MWPB * MNP * MGSLOT * sizeof(double);
+}
+
+int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
+                        uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
+                        uint8_t* cand_ok, int32_t* ncand, hipStream_t st)
+{
+    SclArgs a{};
+    a.dbg = nullptr;
+    a.llr = llr; a.is_f64 = (dtype == ES_DTYPE_F64); a.B = B;
+    a.frozen = ctx->frozen; a.data_pos = ctx->d_data_pos; a.exp_tab = ctx->d_exp_tab;
+    a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
+    a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
+    a.skip_if_hard_ok = skip_if_hard_ok;
+    switch (L) {
+        case 1: return launch_multi<1>(ctx, a, B, st);
+        case 2: return launch_multi<2>(ctx, a, B, st);
+        case 4: return launch_multi<4>(ctx, a, B, st);
+        case 8: return launch_multi<8>(ctx, a, B, st);
+        default: ctx->err = "the multi-frame list decoder serves list sizes 1, 2, 4, 8"; return ES_EINVAL;
+    }
+}

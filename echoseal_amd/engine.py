@@ -66,6 +66,10 @@ class RxEngine:
             self._ctx, ba.ctypes.data, tpl.ctypes.data, taps.ctypes.data, ntaps.ctypes.data,
             frozen.ctypes.data), "es_set_tables")
 
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning knobs of the native library (results never depend on them); see include/echoseal_hip.h."""
+        nat.check(self._ctx, self._lib.es_set_option(self._ctx, name.encode(), int(value)), "es_set_option")
+
     def close(self) -> None:
         if getattr(self, "_ctx", None):
             self._lib.es_destroy(self._ctx)

@@ -151,6 +151,11 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
 int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8_t* code_dev,
                           void* stream);
 
+/* Tuning knobs; results never depend on them.  "scl_multi": -1 (default) lets es_scl_batch choose between one
+ * frame per wavefront and 16/L frames per wavefront (list sizes <= 8; better lane use at the bottom of the LLR
+ * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.                                   */
+int es_set_option(es_ctx* ctx, const char* name, int value);
+
 /* ---- the step after the list decoder ------------------------------------------------
  * Payload validator: replaces the Python closure the reference passes to PolarCode.decode
  * (rtwm/detector.py:168-176): SecureChannel.open (rtwm/crypto.py:39-43: blob = nonce 12 | ciphertext 27 | tag 16,

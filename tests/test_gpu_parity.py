@@ -548,3 +548,37 @@ def test_select_kernel_vs_oracle_and_host_rules(engine, oracle, L):
             assert hp == wp and bool(hok) == (wok == 1)
             seen.add((wok, ww == -1))
         assert len(seen) >= 3
+
+
+@pytest.mark.parametrize("L", [1, 2, 4, 8])
+def test_scl_multi_frames_per_wave(engine, oracle, L):
+    """es_scl_multi.hip (16/L frames per wavefront) returns exactly what the one-frame-per-wave kernel and the oracle
+    return: random LLRs, clipped LLRs (exact ties), hard-decision hits mixed in (skipped frames inside a wave), a batch
+    size that is not a multiple of the frames per wave, float32 and float64 inputs."""
+    rng = np.random.default_rng(100 + L)
+    B = 16 * 13 + 5
+    llr = np.clip(rng.normal(0, 4, (B, 1024)), -12, 12).astype(np.float32)
+    llr[::7] = np.clip(llr[::7] * 6, -12, 12)                       # heavily clipped rows
+    info = rng.integers(0, 256, (B, 55), dtype=np.uint8)
+    code = engine.polar_encode(torch.from_numpy(info).to(engine.device)).cpu().numpy()
+    hit = np.arange(B) % 5 == 2                                     # rows whose hard decision passes the CRC
+    llr[hit] = ((code[hit].astype(np.float32) * 2 - 1) * 3.0)
+    for dtype in (torch.float32, torch.float64):
+        x = torch.from_numpy(llr).to(engine.device).to(dtype)
+        for skip in (True, False):
+            engine.set_option("scl_multi", 0)
+            ref = engine.scl(x, list_size=L, skip_if_hard_ok=skip)
+            engine.set_option("scl_multi", 1)
+            got = engine.scl(x, list_size=L, skip_if_hard_ok=skip)
+            engine.set_option("scl_multi", -1)
+            for name in ("hard_info", "hard_ok", "ncand", "cand_info", "cand_metric", "cand_ok"):
+                assert torch.equal(getattr(ref, name), getattr(got, name)), (name, L, dtype, skip)
+            assert bool(torch.all(got.hard_ok[torch.from_numpy(hit).to(engine.device)] == 1))
+    for i in range(0, B, 41):
+        if hit[i]:
+            continue
+        nn, ci, cm, cc = oracle.scl_list(llr[i].astype(np.float64), L)
+        assert int(got.ncand[i]) == nn
+        assert np.array_equal(np.packbits(ci[:nn], axis=1), got.cand_info[i, :nn].cpu().numpy())
+        assert np.array_equal(cm[:nn], got.cand_metric[i, :nn].cpu().numpy())
+        assert np.array_equal(cc[:nn], got.cand_ok[i, :nn].cpu().numpy())
