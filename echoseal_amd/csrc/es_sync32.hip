@@ -40,6 +40,8 @@ constexpr int XC_WAVES = 4;
 #define XC_GRID_PER_CU 16                            // blocks per CU the grid is capped at (grid-stride beyond)
 #endif
 constexpr int XC_MIN_WAVES = 4;                     // waves per SIMD the register allocation must allow
+constexpr int XC_T_WINDOW = 2048;                   // BASELINE config 3: 2 048-sample windows (1 986 lags)
+constexpr int XC_R_WINDOW = 17;                     // two waves per window: 2 x 64 x 17 = 2 176 >= 1 986 lags (19 would compute 2 432)
 constexpr int XC_R_SMALL = 5;                       // lags per lane of the small-batch screen kernel
 constexpr double DELTA = 3e-5;
 
@@ -446,12 +448,16 @@ int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uin
     const long long cap = (long long)ctx->num_cu * XC_GRID_PER_CU;
     // fewer single-segment items than two waves per SIMD: split records four ways
     const bool small = B * ((n_lags + XC_SEG - 1) / XC_SEG) < (long long)ctx->num_cu * 8;
-    const int seg = small ? 64 * XC_R_SMALL : XC_SEG;
+    const bool win2k = !small && T == XC_T_WINDOW;              // config-3 windows: two waves per window, 17 lags per lane, compile-time bounds
+    const int seg = small ? 64 * XC_R_SMALL : (win2k ? 64 * XC_R_WINDOW : XC_SEG);
     const long long nseg = (n_lags + seg - 1) / seg;
     long long blocks = (B * nseg + XC_WAVES - 1) / XC_WAVES;
     if (blocks > cap) blocks = cap;
     if (small)
         hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_SMALL, 0>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32);
+    else if (win2k)
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_WINDOW, XC_T_WINDOW>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
                            (long long)B, T, band, ctx->d_tables, corr32);
     else if (T == ES_FRAME_LEN)
         hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, ES_FRAME_LEN>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
