@@ -82,6 +82,7 @@ def main() -> None:
     ap.add_argument("--list-size", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scl-streams", type=int, default=2, help="list-decoder streams (= batches in flight) of the pipeline")
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: = --scl-streams)")
     ap.add_argument("--scl-multi", type=int, default=-1, help="es_set_option scl_multi: -1 auto, 0 one frame per wave, 1 several")
     a = ap.parse_args()
 
@@ -124,7 +125,7 @@ def main() -> None:
     # them fill the vector unit).
     # thr / peaks are bit-identical to the float64 path.  Every step's outputs are complete at the final sync.
     from echoseal_amd.engine import DecodePipeline
-    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams)
+    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None)
     for e in pipe.scl_engs:
         e.set_option("scl_multi", a.scl_multi)
 

@@ -327,7 +327,7 @@ class DecodePipeline:
     At most `depth` (= scl_streams) batches are in flight.  Results are complete after `wait(result)` / `synchronize()`;
     values are those of decode_batch (same kernels, same order per batch)."""
 
-    def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2):
+    def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None):
         self.eng = eng
         self.list_size = int(list_size)
         dev = eng.device
@@ -340,7 +340,7 @@ class DecodePipeline:
         # runs while only ONE list decoder is resident (two of them fill every SIMD's register file and would
         # starve the short front-end kernels of wave slots), and its own list decoder then starts beside the
         # one still running.
-        self.depth = len(self.backs)
+        self.depth = len(self.backs) if depth is None else max(1, int(depth))
         self._inflight: list = []            # `done` events of the most recent batches
         self._k = 0
 
