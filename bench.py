@@ -172,7 +172,7 @@ def main() -> None:
             # in a loop of nothing but band-pass + correlation, i.e. under sustained ~4 TB/s of HBM traffic, the same
             # launch takes 1.3-1.5x longer: tools/x32_data_dep.py.)
             evs = []
-            for it in range(8):                      # enqueued back to back (no idle gaps: the clocks stay up)
+            for it in range(4):                      # enqueued back to back (no idle gaps: the clocks stay up)
                 yb64, yb = eng.bpf2(xb, bb)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -182,21 +182,19 @@ def main() -> None:
                 evs.append((e0, e1))
                 del yb64, yb, cb, picked
             torch.cuda.synchronize()
-            ms = [e0.elapsed_time(e1) for e0, e1 in evs[3:]]
+            ms = [e0.elapsed_time(e1) for e0, e1 in evs[1:]]
             m = float(np.mean(ms))
             return bytes_per_record * xb.shape[0] / (m * 1e-3) / 1e9, m
         Bb = 65536
         reps = -(-Bb // B)
         bb = band_d.repeat(reps)[:Bb].contiguous()
-        # (i) BASELINE config 3 shape: 65 536 windows of W = 2048 float32 samples (a frame somewhere inside, noise
-        #     elsewhere): 4*2048 B in + 4*1986 B out = 16 136 algorithmic bytes per window
+        # BASELINE config 3 shape: 65 536 windows of W = 2048 float32 samples (a frame somewhere inside, noise
+        # elsewhere): 4*2048 B in + 4*1986 B out = 16 136 algorithmic bytes per window
         gen = torch.Generator(device=dev); gen.manual_seed(4)
         win = torch.randn((Bb, 2048), device=dev, dtype=torch.float32, generator=gen) * 0.05
         win[:, 400:400 + 1215] += frames_d.repeat(reps, 1)[:Bb]
         big, big_ms = _launch_rate(win, bb, 4 * 2048 + 4 * (2048 - 62))
         del win
-        # (ii) the same number of frame-sized records (T = 1215, 9 472 B each)
-        big_f, big_f_ms = _launch_rate(frames_d.repeat(reps, 1)[:Bb].contiguous(), bb, XCORR_BYTES_PER_FRAME)
     # sanity on the results of the last step (not timed): clean frames sync at offset 0
     ok_sync = bool(torch.all((npeaks >= 1) & (npeaks < 32)).item() and torch.all(peaks[:, 0] == 0).item())
     listed = int((res.ncand > 0).sum().item())
@@ -232,9 +230,7 @@ def main() -> None:
                             "unit": "GB/s", "frac": big / HBM_PEAK_GBS, "launch_ms": big_ms,
                             "note": "same kernel on a BASELINE config-3 sized launch, outside the timed region: 65 536 "
                                     "windows of 2 048 float32 samples, 16 136 algorithmic bytes per window; timed "
-                                    "inside the sync stage (band-pass, screen, exact picking), mean of 5 rounds after 3 warm-up rounds",
-                            "frame_sized_records": {"achieved": big_f, "frac": big_f / HBM_PEAK_GBS, "launch_ms": big_f_ms,
-                                                    "note": "65 536 records of 1 215 samples, 9 472 B each"}},
+                                    "inside the sync stage (band-pass, screen, exact picking), mean of 3 rounds after a warm-up round"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_h, band_d.cpu().numpy(), pn_d.cpu().numpy(), L)
