@@ -8,7 +8,7 @@
 //   es_xcorr32_kernel   y32 (float32, written by the band-pass next to y64) -> corr32 (float32).
 //                       4 860 B in, 4 612 B out per record: the traffic SURVEY.md section 8(d)
 //                       prices the correlation kernel at.  FP32 FMAs, taps in scalar registers.
-//   es_pick_exact_kernel  works on corr32 with a rigorous error bound DELTA (|corr32 - corr64| <=
+//   es_pick_exact_wave_kernel  works on corr32 with a rigorous error bound DELTA (|corr32 - corr64| <=
 //                       DELTA), and re-evaluates in float64 -- with exactly the arithmetic of
 //                       es_xcorr_kernel / oracle/c/eso_dsp.c -- every value that lies within reach
 //                       of a decision: the order statistics' neighbourhoods (order statistics are
@@ -49,7 +49,7 @@ constexpr double DELTA = 3e-5;
 // R = lags per lane.  R = 19 (one wave per frame-sized record) moves the fewest LDS bytes per FMA and is the
 // large-batch kernel; R = 5 spreads a record over four waves so that a 1 024-record launch still puts four
 // waves on every SIMD (latency-bound regime).  The screen value may differ in the last ulps between the two
-// (energy summation order); both satisfy the DELTA bound, and es_pick_exact_kernel is exact for either.
+// (energy summation order); both satisfy the DELTA bound, and es_pick_exact_wave_kernel is exact for either.
 // TC = record length known at compile time (0: use the argument).  With TC = 1 215 (a frame) every bounds
 // test of the load / store loops folds away.
 template <int R, int TC>
@@ -199,9 +199,7 @@ __device__ double corr64_at(const double* __restrict__ yr, int i, const double* 
 }
 
 // ------------------------------------------------------------------------------------ pick (exact)
-constexpr int PX_THREADS = 256;
 constexpr int PX_MAXN = 4096;
-constexpr int PX_CAP = 192;                         // ambiguous values a record may have before it is flagged
 
 __device__ __forceinline__ uint32_t f32_key(float x)
 {
@@ -214,229 +212,266 @@ __device__ __forceinline__ float key_f32(uint32_t k)
     float x; __builtin_memcpy(&x, &b, 4); return x;
 }
 
-struct PxShared {
-    float    row[PX_MAXN];
-    uint32_t hist[256];
-    uint32_t pref;
-    int      k;
-    int      list[PX_CAP];
-    double   val[PX_CAP];
-    double   res[2];
-    int      cnt, below, flag;
-    double   cand_val;
-    int      taken[8];
+// One WAVE per record (a block-per-record version spent its time in ~100 block barriers per record): the float32
+// row sits in LDS, order statistics are 8-bit-digit radix selects on per-wave LDS histograms (ds_add, wave scan, no
+// barrier), band / candidate lists are built with ballots, and all the float64 re-evaluations of a step run in
+// parallel, one per lane.
+//   Order statistics: |screen - exact| <= d, and order statistics are 1-Lipschitz in the sup norm, so the exact k-th
+//   value is the (k - #below)-th of the exact values of the band [m32 - 2d, m32 + 2d] around the float32 order statistic.
+// Records that would need more than PW_CAP exact values (or more than 64 rivals of one candidate) are flagged
+// (reason codes 1..5) and redone by the float64 kernels inside the same es_pick_exact_batch call.
+constexpr int PW_WAVES = 4;
+constexpr int PW_CAP = 192;
+
+constexpr int PW_HCOPIES = 4;                       // private copies of the histogram (lane & 3): the leading byte of a
+                                                    // correlation value takes a handful of values, and 64 lanes adding to
+                                                    // one LDS word serialise
+struct PwFixed {
+    uint32_t hist[PW_HCOPIES][256];
+    int      list[PW_CAP];
+    double   val[PW_CAP];
 };
 
-// k-th smallest 32-bit key of key(i), i in [0,n): 4 passes of 8 bits (LDS histogram + wave scan)
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// k-th smallest 32-bit key of key(i), i in [0,n), by one wave: 4 passes of 8 bits
 template <typename F>
-__device__ uint32_t px_select(PxShared& S, int n, int k, F key)
+__device__ uint32_t pw_select(PwFixed& S, int n, int k, int lane, F key)
 {
     uint32_t prefix = 0;
     int kk = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        S.hist[threadIdx.x] = 0;
-        __syncthreads();
+        #pragma unroll
+        for (int b = 0; b < 4 * PW_HCOPIES; ++b) (&S.hist[0][0])[lane + 64 * b] = 0;
+        wave_fence_lds();
         const uint32_t himask = (shift == 24) ? 0u : (~0u << (shift + 8));
-        for (int i = threadIdx.x; i < n; i += PX_THREADS) {
+        uint32_t* const myh = S.hist[lane & (PW_HCOPIES - 1)];
+        for (int i = lane; i < n; i += 64) {
             const uint32_t kx = key(i);
-            if ((kx & himask) == prefix) atomicAdd(&S.hist[(kx >> shift) & 255u], 1u);
+            if ((kx & himask) == prefix) atomicAdd(&myh[(kx >> shift) & 255u], 1u);
         }
-        __syncthreads();
-        {
-            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-            const uint32_t h = S.hist[threadIdx.x];
-            uint32_t incl = h;
+        wave_fence_lds();
+        uint32_t h[4];
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) {                                    // lane owns four consecutive bins
+            uint32_t t = 0;
             #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-            __syncthreads();
-            if (lane == 63) S.hist[wv] = incl;
-            __syncthreads();
-            uint32_t basec = 0;
-            for (int w = 0; w < wv; ++w) basec += S.hist[w];
-            incl += basec;
-            const uint32_t excl = incl - h;
-            if ((int)excl <= kk && kk < (int)incl) { S.k = kk - (int)excl; S.pref = prefix | ((uint32_t)threadIdx.x << shift); }
+            for (int cpy = 0; cpy < PW_HCOPIES; ++cpy) t += S.hist[cpy][4 * lane + b];
+            h[b] = t;
         }
-        __syncthreads();
-        prefix = S.pref; kk = S.k;
-        __syncthreads();
+        const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
+        uint32_t incl = s4;
+        #pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        const uint32_t excl = incl - s4;
+        const bool hit = ((int)excl <= kk) && (kk < (int)incl);
+        int bin = 0, nk = 0;
+        if (hit) {
+            uint32_t c = excl;
+            #pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (kk >= (int)c && kk < (int)(c + h[b])) { bin = 4 * lane + b; nk = kk - (int)c; }
+                c += h[b];
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        const int src = __ffsll((long long)m) - 1;
+        bin = __shfl(bin, src); kk = __shfl(nk, src);
+        prefix |= (uint32_t)bin << shift;
+        wave_fence_lds();
     }
     return prefix;
 }
 
-// Exact order statistics k_lo <= k_hi of exact(i) given a screen(i) with |screen - exact| <= d:
-// band = screen within [m_lo - 2d, m_hi + 2d]; exact values of the band are ranked by counting.
-// Returns false (record must be flagged) when the band does not fit.  Results in S.res[0..1].
+// Exact order statistics k_lo <= k_hi of exact(i) from a screen with |screen - exact| <= d.  Results in r0, r1;
+// false = the band does not fit (record must be flagged).
 template <typename FS, typename FE>
-__device__ bool px_exact_stats(PxShared& S, int n, int k_lo, int k_hi, double d, FS screen, FE exact)
+__device__ bool pw_exact_stats(PwFixed& S, int n, int k_lo, int k_hi, double d, int lane, FS screen, FE exact,
+                               double& r0, double& r1)
 {
     auto key = [&](int i) { return f32_key((float)screen(i)); };
-    const float m_lo = key_f32(px_select(S, n, k_lo, key));
-    const float m_hi = (k_hi == k_lo) ? m_lo : key_f32(px_select(S, n, k_hi, key));
-    // (float) rounding of the screen value costs at most 2^-24 relative: folded into the margin
+    const uint32_t key_lo = pw_select(S, n, k_lo, lane, key);
+    const float m_lo = key_f32(key_lo);
+    float m_hi = m_lo;
+    if (k_hi != k_lo) {
+        // k_hi = k_lo + 1: the next order statistic is m_lo itself if enough keys are <= m_lo, else the smallest
+        // key above it -- one pass of counting instead of a second radix select
+        int le = 0; uint32_t nxt = 0xffffffffu;
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t kx = key(i);
+            le += kx <= key_lo;
+            if (kx > key_lo && kx < nxt) nxt = kx;
+        }
+        #pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            le += __shfl_xor(le, o);
+            const uint32_t on = (uint32_t)__shfl_xor((int)nxt, o);
+            nxt = on < nxt ? on : nxt;
+        }
+        m_hi = (le > k_hi) ? m_lo : key_f32(nxt);
+    }
     const double lo = (double)m_lo - 2.0 * d - 1e-6 * __builtin_fabs((double)m_lo);
     const double hi = (double)m_hi + 2.0 * d + 1e-6 * __builtin_fabs((double)m_hi);
-    if (threadIdx.x == 0) { S.cnt = 0; S.below = 0; }
-    __syncthreads();
-    int below = 0;
-    for (int i = threadIdx.x; i < n; i += PX_THREADS) {
-        const double v = screen(i);
-        if (v < lo) ++below;
-        else if (v <= hi) { const int slot = atomicAdd(&S.cnt, 1); if (slot < PX_CAP) S.list[slot] = i; }
+    int below = 0, nb = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < n;
+        const double v = in ? screen(i) : 0.0;
+        const bool isb = in && v < lo;
+        const bool inb = in && !(v < lo) && v <= hi;
+        below += __popcll(__ballot(isb));
+        const unsigned long long mb = __ballot(inb);
+        const int pos = nb + lanes_below(mb);
+        if (inb && pos < PW_CAP) S.list[pos] = i;
+        nb += __popcll(mb);
     }
-    atomicAdd(&S.below, below);
-    __syncthreads();
-    const int nb = S.cnt;
-    if (nb > PX_CAP) return false;
-    if ((int)threadIdx.x < nb) S.val[threadIdx.x] = exact(S.list[threadIdx.x]);
-    __syncthreads();
-    const int r_lo = k_lo - S.below, r_hi = k_hi - S.below;
-    if ((int)threadIdx.x < nb) {
-        const double v = S.val[threadIdx.x];
+    if (nb > PW_CAP) return false;
+    wave_fence_lds();
+    for (int idx = lane; idx < nb; idx += 64) S.val[idx] = exact(S.list[idx]);
+    wave_fence_lds();
+    const int r_lo = k_lo - below, r_hi = k_hi - below;
+    double c0 = 0.0, c1 = 0.0; bool h0 = false, h1 = false;
+    for (int idx = lane; idx < nb; idx += 64) {
+        const double v = S.val[idx];
         int less = 0, eq = 0;
-        for (int j = 0; j < nb; ++j) { less += S.val[j] < v; eq += S.val[j] == v; }
-        if (less <= r_lo && r_lo < less + eq) S.res[0] = v;
-        if (less <= r_hi && r_hi < less + eq) S.res[1] = v;
+        for (int j = 0; j < nb; ++j) { const double vj = S.val[j]; less += vj < v; eq += vj == v; }
+        if (less <= r_lo && r_lo < less + eq) { c0 = v; h0 = true; }
+        if (less <= r_hi && r_hi < less + eq) { c1 = v; h1 = true; }
     }
-    __syncthreads();
+    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+    r0 = __shfl(c0, m0 ? __ffsll((long long)m0) - 1 : 0);
+    r1 = __shfl(c1, m1 ? __ffsll((long long)m1) - 1 : 0);
+    wave_fence_lds();
     return true;
 }
 
-__global__ __launch_bounds__(PX_THREADS) void es_pick_exact_kernel(const float* __restrict__ corr32,
+__global__ __launch_bounds__(64 * PW_WAVES) void es_pick_exact_wave_kernel(const float* __restrict__ corr32,
         const double* __restrict__ y, long long B, int T, const uint8_t* __restrict__ band,
         const es_band_tables* __restrict__ tabs, double* __restrict__ thr_out, int32_t* __restrict__ peaks,
         int32_t* __restrict__ npeaks, uint8_t* __restrict__ flags)
 {
-    __shared__ PxShared S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
     const int n = T - (ES_PRE_L - 1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t per_wave = sizeof(PwFixed) + (((size_t)n * 4 + 15) & ~(size_t)15);
+    PwFixed& S = *reinterpret_cast<PwFixed*>(pw_smem + wv * per_wave);
+    float* const c = reinterpret_cast<float*>(pw_smem + wv * per_wave + sizeof(PwFixed));
     const int min_distance = ES_FRAME_LEN / 2;
-    for (long long rec = blockIdx.x; rec < B; rec += gridDim.x) {
+    const long long stride = (long long)gridDim.x * PW_WAVES;
+    for (long long rec = (long long)blockIdx.x * PW_WAVES + wv; rec < B; rec += stride) {
         const float* cg = corr32 + rec * n;
         const double* yr = y + rec * T;
         const double* tpl = tabs->tpl[band[rec]];
         int bad = 0;
-        for (int i = threadIdx.x; i < n; i += PX_THREADS) {
+        for (int i = lane; i < n; i += 64) {
             const float v = cg[i];
-            S.row[i] = v;
+            c[i] = v;
             bad |= !(__builtin_fabsf(v) < 1e30f);                       // inf / nan / absurd: screen unusable
         }
-        if (__syncthreads_or(bad)) {
-            if (threadIdx.x == 0) flags[rec] = 1;                        // reason 1: non-finite screen
-            __syncthreads();
-            continue;
-        }
-        const float* c = S.row;
+        wave_fence_lds();
+        if (__ballot(bad)) { if (lane == 0) flags[rec] = 1; continue; }   // reason 1: non-finite screen
         auto exact_corr = [&](int i) { return corr64_at(yr, i, tpl); };
         const int k_hi = n / 2, k_lo = (n & 1) ? n / 2 : n / 2 - 1;
 
-        // ---- median (exact)
-        bool ok = px_exact_stats(S, n, k_lo, k_hi, DELTA, [&](int i) { return (double)c[i]; }, exact_corr);
-        double med = 0.0, mad = 0.0;
-        int why = 2;                                                     // reason 2: median band too wide
-        if (ok) {
-            why = 3;                                                     // reason 3: MAD band too wide
-            med = (n & 1) ? S.res[0] : (S.res[0] + S.res[1]) / 2.0;
-            __syncthreads();
-            // ---- MAD (exact): |corr64 - med| screened by |corr32 - med|
-            ok = px_exact_stats(S, n, k_lo, k_hi, DELTA, [&](int i) { return __builtin_fabs((double)c[i] - med); },
-                                [&](int i) { return __builtin_fabs(corr64_at(yr, i, tpl) - med); });
-            if (ok) mad = ((n & 1) ? S.res[0] : (S.res[0] + S.res[1]) / 2.0) + 1e-12;
-        }
-        if (!ok) {
-            if (threadIdx.x == 0) flags[rec] = (uint8_t)why;
-            __syncthreads();
+        // ---- median and MAD (exact)
+        double r0, r1;
+        if (!pw_exact_stats(S, n, k_lo, k_hi, DELTA, lane, [&](int i) { return (double)c[i]; }, exact_corr, r0, r1)) {
+            if (lane == 0) flags[rec] = 2;                               // reason 2: median band too wide
             continue;
         }
+        const double med = (n & 1) ? r0 : (r0 + r1) / 2.0;
+        if (!pw_exact_stats(S, n, k_lo, k_hi, DELTA, lane, [&](int i) { return __builtin_fabs((double)c[i] - med); },
+                            [&](int i) { return __builtin_fabs(corr64_at(yr, i, tpl) - med); }, r0, r1)) {
+            if (lane == 0) flags[rec] = 3;                               // reason 3: MAD band too wide
+            continue;
+        }
+        const double mad = ((n & 1) ? r0 : (r0 + r1) / 2.0) + 1e-12;
         double thr = med + 4.5 * 1.4826 * mad;
         if (0.95 < thr) thr = 0.95;
-        __syncthreads();
 
         // ---- threshold crossers in ascending order; each one is settled exactly
         int total = 0;
         bool overflow = false;
-        for (int base = 0; base < n && !overflow; base += PX_THREADS) {
-            const int i = base + threadIdx.x;
+        for (int base = 0; base < n && !overflow; base += 64) {
+            const int i = base + lane;
             const bool cand = (i < n) && ((double)c[i] >= thr - DELTA);
-            if (threadIdx.x == 0) S.cnt = 0;
-            __syncthreads();
-            const unsigned long long bal = __ballot(cand);
-            if ((threadIdx.x & 63) == 0) { ((unsigned long long*)S.val)[threadIdx.x >> 6] = bal; if (bal) atomicOr((unsigned int*)&S.cnt, 1u); }
-            __syncthreads();
-            if (S.cnt == 0) continue;
-            unsigned long long mask[PX_THREADS / 64];
-            #pragma unroll
-            for (int w = 0; w < PX_THREADS / 64; ++w) mask[w] = ((unsigned long long*)S.val)[w];
-            __syncthreads();
-            for (int w = 0; w < PX_THREADS / 64 && !overflow; ++w) {
-                unsigned long long m = mask[w];
-                while (m) {
-                    const int bit = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int ci = base + 64 * w + bit;
-                    if (threadIdx.x == 0) S.cand_val = corr64_at(yr, ci, tpl);
-                    __syncthreads();
-                    const double cv = S.cand_val;
-                    __syncthreads();
-                    if (cv < thr) continue;                              // uniform
-                    int lo = ci - min_distance; if (lo < 0) lo = 0;
-                    int hi = ci + min_distance + 1; if (hi > n) hi = n;
-                    int bigger = 0, amb = 0;
-                    for (int j = lo + threadIdx.x; j < hi; j += PX_THREADS) {
-                        const double s32 = (double)c[j];
-                        if (s32 > cv + DELTA) bigger = 1;
-                        else if (s32 >= cv - DELTA && j != ci) {         // rival within reach: settle exactly
-                            ++amb;
-                            if (amb <= 4) bigger |= (corr64_at(yr, j, tpl) > cv);
-                        }
-                    }
-                    const int too_many = __syncthreads_or(amb > 4);
-                    if (too_many) { overflow = true; break; }
-                    if (__syncthreads_or(bigger) == 0) {
-                        if (threadIdx.x == 0 && total < ES_MAX_PEAKS) peaks[rec * ES_MAX_PEAKS + total] = ci;
-                        ++total;
-                    }
+            unsigned long long m = __ballot(cand);
+            if (!m) continue;
+            const double cv_mine = cand ? corr64_at(yr, i, tpl) : 0.0;   // all candidates of the chunk at once
+            while (m && !overflow) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int ci = base + bit;
+                const double cv = __shfl(cv_mine, bit);
+                if (cv < thr) continue;
+                int lo = ci - min_distance; if (lo < 0) lo = 0;
+                int hi = ci + min_distance + 1; if (hi > n) hi = n;
+                bool bigger = false;
+                int namb = 0;
+                for (int j0 = lo; j0 < hi && !bigger; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool in = j < hi;
+                    const double s32 = in ? (double)c[j] : 0.0;
+                    const bool big = in && s32 > cv + DELTA;
+                    const bool amb = in && !big && s32 >= cv - DELTA && j != ci;   // rival within reach: settle exactly
+                    if (__ballot(big)) { bigger = true; break; }
+                    const unsigned long long ma = __ballot(amb);
+                    const int pos = namb + lanes_below(ma);
+                    if (amb && pos < 64) S.list[pos] = j;
+                    namb += __popcll(ma);
                 }
+                if (bigger) continue;
+                if (namb > 64) { overflow = true; break; }
+                if (namb > 0) {
+                    wave_fence_lds();
+                    const bool have = lane < namb;
+                    const double jv = have ? corr64_at(yr, S.list[lane], tpl) : 0.0;
+                    const bool beats = have && jv > cv;
+                    wave_fence_lds();
+                    if (__ballot(beats)) continue;
+                }
+                if (lane == 0 && total < ES_MAX_PEAKS) peaks[rec * ES_MAX_PEAKS + total] = ci;
+                ++total;
             }
         }
-        if (overflow) {
-            if (threadIdx.x == 0) flags[rec] = 4;                        // reason 4: too many rivals within DELTA
-            __syncthreads();
-            continue;
-        }
+        if (overflow) { if (lane == 0) flags[rec] = 4; continue; }       // reason 4: too many rivals within DELTA
 
         if (total == 0) {
             // ---- fallback: five largest exact correlations (descending; equal values -> higher index)
             const int kmax = n < 5 ? n : 5;
-            const float t5 = key_f32(px_select(S, n, n - kmax, [&](int i) { return f32_key(c[i]); }));
+            const float t5 = key_f32(pw_select(S, n, n - kmax, lane, [&](int i) { return f32_key(c[i]); }));
             const double lo = (double)t5 - 2.0 * DELTA;
-            if (threadIdx.x == 0) S.cnt = 0;
-            __syncthreads();
-            for (int i = threadIdx.x; i < n; i += PX_THREADS)
-                if ((double)c[i] >= lo) { const int slot = atomicAdd(&S.cnt, 1); if (slot < PX_CAP) S.list[slot] = i; }
-            __syncthreads();
-            const int nb = S.cnt;
-            if (nb > PX_CAP) {
-                if (threadIdx.x == 0) flags[rec] = 5;                    // reason 5: fallback list too long
-                __syncthreads();
-                continue;
+            int nb = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                const bool in = (i < n) && ((double)c[i] >= lo);
+                const unsigned long long mb = __ballot(in);
+                const int pos = nb + lanes_below(mb);
+                if (in && pos < PW_CAP) S.list[pos] = i;
+                nb += __popcll(mb);
             }
-            if ((int)threadIdx.x < nb) S.val[threadIdx.x] = corr64_at(yr, S.list[threadIdx.x], tpl);
-            __syncthreads();
-            if ((int)threadIdx.x < nb) {
-                const double v = S.val[threadIdx.x]; const int idx = S.list[threadIdx.x];
+            if (nb > PW_CAP) { if (lane == 0) flags[rec] = 5; continue; }   // reason 5: fallback list too long
+            wave_fence_lds();
+            for (int idx = lane; idx < nb; idx += 64) S.val[idx] = corr64_at(yr, S.list[idx], tpl);
+            wave_fence_lds();
+            for (int idx = lane; idx < nb; idx += 64) {
+                const double v = S.val[idx]; const int ii = S.list[idx];
                 int before = 0;                                          // how many sort ahead of me
                 for (int j = 0; j < nb; ++j) {
                     const double vj = S.val[j]; const int ij = S.list[j];
-                    before += (vj > v) || (vj == v && ij > idx);
+                    before += (vj > v) || (vj == v && ij > ii);
                 }
-                if (before < kmax) peaks[rec * ES_MAX_PEAKS + before] = idx;
+                if (before < kmax) peaks[rec * ES_MAX_PEAKS + before] = ii;
             }
-            if (threadIdx.x == 0) npeaks[rec] = kmax | (1 << 30);
-        } else if (threadIdx.x == 0) {
+            if (lane == 0) npeaks[rec] = kmax | (1 << 30);
+            wave_fence_lds();
+        } else if (lane == 0) {
             npeaks[rec] = total;
         }
-        if (threadIdx.x == 0) { thr_out[rec] = thr; flags[rec] = 0; }
-        __syncthreads();
+        if (lane == 0) { thr_out[rec] = thr; flags[rec] = 0; }
     }
 }
 
@@ -473,10 +508,19 @@ int es_launch_pick_exact(es_ctx* ctx, const float* corr32, const double* y, int6
                          double* thr, int32_t* peaks, int32_t* npeaks, uint8_t* flags, hipStream_t st)
 {
     if (T - (ES_PRE_L - 1) > PX_MAXN) { ctx->err = "es_pick_exact_batch: more than 4096 lags; use the float64 path"; return ES_EINVAL; }
-    long long blocks = B;
+    const int n = T - (ES_PRE_L - 1);
+    const size_t per_wave = sizeof(PwFixed) + (((size_t)n * 4 + 15) & ~(size_t)15);
+    const size_t lds = per_wave * PW_WAVES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_pick_exact_wave_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PW_WAVES * (sizeof(PwFixed) + PX_MAXN * 4))));
+        attr_set = true;
+    }
+    long long blocks = (B + PW_WAVES - 1) / PW_WAVES;
     const long long cap = (long long)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(es_pick_exact_kernel, dim3((unsigned)blocks), dim3(PX_THREADS), 0, st, corr32, y, (long long)B, T,
+    hipLaunchKernelGGL(es_pick_exact_wave_kernel, dim3((unsigned)blocks), dim3(64 * PW_WAVES), lds, st, corr32, y, (long long)B, T,
                        band, ctx->d_tables, thr, peaks, npeaks, flags);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
