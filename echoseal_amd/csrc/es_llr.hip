@@ -256,6 +256,12 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
     __shared__ float s_pn[NPAY];
     __shared__ float s_win[MAX_WIN];
     __shared__ float s_abs[MAX_WIN];
+    __shared__ double s_pre[MAX_WIN + 1];            // float64 prefix sums of |win| (shift-search screen)
+    __shared__ double s_A[2 * ES_MAX_TAPS + 8];      // exact-sum score per shift
+    __shared__ int    s_cand[2 * ES_MAX_TAPS + 8];   // shifts that get the float32 NumPy-order evaluation
+    __shared__ double s_wtot[4];
+    __shared__ double s_top[4][2];
+    __shared__ int    s_wcnt[4];
     __shared__ float s_d[NPAY];
     __shared__ float s_score[4][2];
     __shared__ int   s_shift[4];
@@ -354,10 +360,75 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         pw_plan_build(plan, n - guard);
         const float cnt_f = (float)(n - guard);
         const PwLane geo = pw_lane(plan, lane);
+        // Screen: a float32 pairwise sum of non-negative terms is within (1+2^-24)^30 - 1 < 1.8e-6 (relative) of the
+        // exact sum (no element passes through more than 29 additions: 15 in its accumulator, 3 combining, <= 7
+        // trailing, 4 tree levels; plus the division), and the exact window sums of all shifts come from ONE float64
+        // prefix sum.  Only shifts whose exact-sum score is within SCREEN_R of the runner-up can be the winner or the
+        // runner-up that the kernel reports; those -- usually two to four of the ~260 -- get the NumPy-order float32
+        // evaluation.  Flat or non-finite data simply leaves every shift a candidate.
+        constexpr double SCREEN_R = 4e-6;
+        {
+            const int chunk = (nwin + LLR_THREADS - 1) / LLR_THREADS;
+            const int j0 = tid * chunk, j1 = (j0 + chunk < nwin) ? j0 + chunk : nwin;
+            double ls = 0.0;
+            for (int j = j0; j < j1; ++j) ls += (double)s_abs[j];
+            double incl = ls;
+            #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            if (lane == 63) s_wtot[wv] = incl;
+            __syncthreads();
+            double run = incl - ls;
+            for (int w = 0; w < wv; ++w) run += s_wtot[w];
+            if (tid == 0) s_pre[0] = 0.0;
+            for (int j = j0; j < j1; ++j) { run += (double)s_abs[j]; s_pre[j + 1] = run; }
+            __syncthreads();
+        }
+        const int nshift = 2 * max_shift + 1;
+        const bool finite_all = s_pre[nwin] < 1.0e37;                // float32 sums cannot overflow below this
+        double a1 = -1.0, a2 = -1.0;                                 // two largest exact-sum scores (with multiplicity)
+        for (int u = tid; u < nshift; u += LLR_THREADS) {
+            const int i0 = base + (u - max_shift);
+            double A = -1.0;
+            if (i0 >= 0 && i0 + n <= nwin) A = (s_pre[i0 + n] - s_pre[i0 + guard]) / (double)(n - guard);
+            s_A[u] = A;
+            if (A > a1) { a2 = a1; a1 = A; } else if (A > a2) a2 = A;
+        }
+        #pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double o1 = __shfl_xor(a1, o), o2 = __shfl_xor(a2, o);
+            const double hi = a1 > o1 ? a1 : o1, lo = a1 > o1 ? o1 : a1;
+            const double m2 = a2 > o2 ? a2 : o2;
+            a1 = hi; a2 = lo > m2 ? lo : m2;
+        }
+        if (lane == 0) { s_top[wv][0] = a1; s_top[wv][1] = a2; }
+        __syncthreads();
+        a1 = -1.0; a2 = -1.0;
+        #pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            #pragma unroll
+            for (int e = 0; e < 2; ++e) { const double A = s_top[w][e]; if (A > a1) { a2 = a1; a1 = A; } else if (A > a2) a2 = A; }
+        }
+        // A(s) (1 + R) >= A2 (1 - R); with fewer than two valid shifts (a2 < 0) or non-finite data everything stays
+        // (scores down in the float32 subnormal range lose the relative bound: no screening there either)
+        const double tau = (finite_all && a2 >= 1.0e-30) ? a2 * (1.0 - SCREEN_R) : -2.0;
+        int ncand = 0;
+        for (int u0 = 0; u0 < nshift; u0 += LLR_THREADS) {           // ordered compaction, ascending shift
+            const int u = u0 + tid;
+            const bool isc = (u < nshift) && (s_A[u] >= 0.0) && (s_A[u] * (1.0 + SCREEN_R) >= tau);
+            const unsigned long long mb = __ballot(isc);
+            if (lane == 0) s_wcnt[wv] = __popcll(mb);
+            __syncthreads();
+            int off = ncand;
+            for (int w = 0; w < wv; ++w) off += s_wcnt[w];
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+            if (isc) s_cand[off + below] = u - max_shift;
+            ncand += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            __syncthreads();
+        }
         float my_best = -1.0f, my_second = -1.0f; int my_s = 0;
-        for (int s = -max_shift + wv; s <= max_shift; s += 4) {      // ascending within a wave
+        for (int ci = wv; ci < ncand; ci += 4) {                     // ascending within a wave
+            const int s = s_cand[ci];
             const int i0 = base + s;
-            if (i0 < 0 || i0 + n > nwin) continue;
             const float sum = wave_pairwise_sum_nonneg(geo, lane, s_abs + i0 + guard);
             const float score = sum / cnt_f;
             if (score > my_best) { my_second = my_best; my_best = score; my_s = s; }

@@ -582,3 +582,29 @@ def test_scl_multi_frames_per_wave(engine, oracle, L):
         assert np.array_equal(np.packbits(ci[:nn], axis=1), got.cand_info[i, :nn].cpu().numpy())
         assert np.array_equal(cm[:nn], got.cand_metric[i, :nn].cpu().numpy())
         assert np.array_equal(cc[:nn], got.cand_ok[i, :nn].cpu().numpy())
+
+
+def test_llr_shift_search_screen_is_exact(engine, oracle):
+    """The LLR kernel scores only the shifts that a float64 exact-sum screen cannot rule out.  Winner, LLRs and BOTH
+    reported scores (best, runner-up) must still equal the oracle, which scores every shift: clean and noisy frames,
+    pure noise (flat score curve), constants (every shift ties), a click, huge and tiny amplitudes."""
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    rng = np.random.default_rng(61)
+    frames, band, pn = _workload(24, noise=0.0)
+    x = frames.astype(np.float64).copy()
+    x[4:8] += rng.normal(0, 0.5, x[4:8].shape)                      # noisy
+    x[8:12] = rng.normal(0, 0.3, x[8:12].shape)                      # noise only
+    x[12] = 0.25                                                     # constant: all shifts tie
+    x[13] = 0.0; x[13, 700] = 1.0                                    # click
+    x[14] *= 1e12; x[15] *= 1e-12; x[16] *= 1e-25
+    x[17] = 0.0
+    x[18] = np.sign(rng.normal(0, 1, 1215)) * 0.1                    # +-0.1: equal magnitudes everywhere
+    x[19] = np.tile(rng.normal(0, 0.2, 27), 45)                      # period 27: repeating scores
+    y, b, p = _dev(engine, x, band, pn)
+    llr, bs, sc = engine.llr(y, b, p, want_diag=True)
+    llr = llr.cpu().numpy(); bs = bs.cpu().numpy(); sc = sc.cpu().numpy()
+    for i in range(len(x)):
+        o, obs, best, second = oracle.llr(x[i], np.unpackbits(pn[i])[191:1215], taps[band[i], :ntaps[band[i]]])
+        assert obs == int(bs[i]), i
+        assert np.array_equal(o, llr[i]), i
+        assert np.float32(best) == sc[i, 0] and np.float32(second) == sc[i, 1], (i, best, second, sc[i])
