@@ -77,6 +77,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_scl_scratch) (void)hipFree(ctx->d_scl_scratch);
     if (ctx->d_ws_corr) (void)hipFree(ctx->d_ws_corr);
     if (ctx->d_wide_scratch) (void)hipFree(ctx->d_wide_scratch);
+    if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
     delete ctx;
 }
 
@@ -290,6 +291,17 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     }
     return es_launch_scl(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                          cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
+}
+
+int es_schedule_batch(es_ctx* ctx, const uint8_t* aes_key16_host, const uint8_t* band_key32_host, const uint32_t* ctr_dev,
+                      uint32_t ctr0, int64_t n, uint8_t* pn_rows_dev, uint8_t* band_dev, void* stream)
+{
+    if (!ctx) return ES_EINVAL;
+    if (n < 0) return fail(ctx, ES_EINVAL, "es_schedule_batch: negative count");
+    if (n == 0) return ES_OK;
+    if (!aes_key16_host || !band_key32_host || !pn_rows_dev || !band_dev) return fail(ctx, ES_EINVAL, "es_schedule_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_schedule(ctx, aes_key16_host, band_key32_host, ctr_dev, ctr0, n, pn_rows_dev, band_dev, (hipStream_t)stream);
 }
 
 int es_set_option(es_ctx* ctx, const char* name, int value)

@@ -50,3 +50,22 @@ def split_schedule(buf: torch.Tensor, lo: int, hi: int) -> tuple[torch.Tensor, t
     """-> (pn_rows [n,152], band [n]) views of this rank's shard, contiguous."""
     mine = buf[lo:hi]
     return mine[:, :152].contiguous(), mine[:, 152].contiguous()
+
+
+def broadcast_keys(keys48: bytes | None, device: torch.device, src: int = 0) -> bytes:
+    """Alternative to broadcasting the expanded schedule: the root passes the 48 bytes of key material
+    (16-byte AES PN sub-key | 32-byte hop key), peers pass None; every rank then derives the rows of its own shard
+    on its GPU with `RxEngine.schedule` (es_schedule_batch).  One 48-byte broadcast instead of 153 B per counter."""
+    buf = torch.zeros(48, dtype=torch.uint8, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_rank() == src:
+            buf.copy_(torch.frombuffer(bytearray(keys48), dtype=torch.uint8))
+        dist.broadcast(buf, src=src)
+    else:
+        buf.copy_(torch.frombuffer(bytearray(keys48), dtype=torch.uint8))
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def derive_shard_schedule(eng, keys48: bytes, lo: int, hi: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """(pn_rows [hi-lo,152], band [hi-lo]) of counters lo..hi-1, generated on the device from the 48 key bytes."""
+    return eng.schedule(keys48[:16], keys48[16:], ctr0=lo, n=hi - lo)

@@ -235,6 +235,26 @@ class RxEngine:
                   "es_polar_encode_batch")
         return code
 
+    # ------------------------------------------------------------------ key / PN / hop schedule
+    def schedule(self, aes_key16: bytes, band_key32: bytes, ctrs=None, *, ctr0: int = 0, n: int | None = None):
+        """PN rows and band indices of frame counters, derived on the device: -> (pn [n,152] uint8, band [n] uint8).
+        `ctrs` (any integer sequence / tensor) or the range ctr0 .. ctr0+n-1.  aes_key16 = StreamPRNG.sub_key,
+        band_key32 = the hop key (rtwm/utils.py:27-36, 115-132)."""
+        if len(aes_key16) != 16 or len(band_key32) != 32:
+            raise ValueError("schedule needs a 16-byte AES key and a 32-byte band key")
+        if ctrs is not None:
+            cd = self._ctr_dev(ctrs); n = cd.numel()
+        elif n is None:
+            raise ValueError("give ctrs or (ctr0, n)")
+        else:
+            cd = None
+        pn = torch.empty((n, 152), dtype=torch.uint8, device=self.device)
+        band = torch.empty(n, dtype=torch.uint8, device=self.device)
+        nat.check(self._ctx, self._lib.es_schedule_batch(self._ctx, bytes(aes_key16), bytes(band_key32), _ptr(cd),
+                                                         int(ctr0) & 0xFFFFFFFF, n, _ptr(pn), _ptr(band), self._stream()),
+                  "es_schedule_batch")
+        return pn, band
+
     # ------------------------------------------------------------------ after the list decoder (SURVEY 8 f-2)
     def _ctr_dev(self, ctrs) -> torch.Tensor:
         """Frame counters as the 32-bit words the kernels compare against (stored in an int32 tensor)."""

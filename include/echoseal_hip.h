@@ -151,6 +151,15 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
 int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8_t* code_dev,
                           void* stream);
 
+/* Key / PN / hop schedule on the device (schedule half of f-3): for each frame counter the 152
+ * packed PN bytes of SecureChannel.pn_bits (rtwm/crypto.py:46-48 -> rtwm/utils.py:115-132: AES-128-ECB of
+ * (ctr << 64 | j), j = 0..9, MSB-first bits) and the band index of choose_band (rtwm/utils.py:27-36:
+ * HMAC-SHA256(band_key, ctr_be32)[0] % 4).  aes_key16_host = StreamPRNG's 16-byte sub-key, band_key32_host = the hop key
+ * (the raw master key in the reference, rtwm/detector.py:31); counters are ctr_dev[i] (uint32) or, when ctr_dev is
+ * NULL, ctr0 + i.  pn_rows_dev [n][152], band_dev [n]: the layout es_llr_batch / es_bpf_batch consume.            */
+int es_schedule_batch(es_ctx* ctx, const uint8_t* aes_key16_host, const uint8_t* band_key32_host, const uint32_t* ctr_dev,
+                      uint32_t ctr0, int64_t n, uint8_t* pn_rows_dev, uint8_t* band_dev, void* stream);
+
 /* Tuning knobs; results never depend on them.  "scl_multi": -1 (default) lets es_scl_batch choose between one
  * frame per wavefront and 16/L frames per wavefront (list sizes <= 8; better lane use at the bottom of the LLR
  * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.                                   */

@@ -178,3 +178,23 @@ def select_validated(key, ctr, hard, hard_ok, cand, cand_ok, cand_metric, n):
     ok = lib().eso_select_validated(kp, ctypes.c_uint32(int(ctr)), _p(_c(hard, np.uint8)), int(hard_ok), _p(cand), _p(cand_ok),
                                     _p(cand_metric), int(n), _p(payload), ctypes.byref(which))
     return payload.tobytes(), int(ok), int(which.value)
+
+
+# ------------------------------------------------------------------------------- key / PN / hop schedule (a18, f-3)
+def aes128_encrypt(key: bytes, block: bytes) -> bytes:
+    rk = np.zeros(176, np.uint8); out = np.zeros(16, np.uint8)
+    lib().eso_aes128_expand(_p(np.frombuffer(key, np.uint8)), _p(rk))
+    lib().eso_aes128_encrypt(_p(rk), _p(np.frombuffer(block, np.uint8)), _p(out)); return out.tobytes()
+
+def hmac_sha256_short(key: bytes, msg: bytes) -> bytes:
+    out = np.zeros(32, np.uint8)
+    lib().eso_hmac_sha256_short(_p(np.frombuffer(key, np.uint8)), len(key), _p(np.frombuffer(msg, np.uint8)), len(msg), _p(out))
+    return out.tobytes()
+
+def schedule_rows(aes_key: bytes, band_key: bytes, ctrs):
+    """-> (pn uint8 [n,152], band uint8 [n]) for 32-bit frame counters."""
+    ctrs = np.asarray(ctrs, dtype=np.uint32); pn = np.zeros((ctrs.size, 152), np.uint8); band = np.zeros(ctrs.size, np.uint8)
+    ak = np.frombuffer(aes_key, np.uint8); bk = np.frombuffer(band_key, np.uint8); b1 = np.zeros(1, np.uint8)
+    for i, c in enumerate(ctrs):
+        lib().eso_schedule_row(_p(ak), _p(bk), ctypes.c_uint32(int(c)), _p(pn[i]), _p(b1)); band[i] = b1[0]
+    return pn, band

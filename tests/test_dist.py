@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from echoseal_amd.dist import ROW, broadcast_schedule, build_schedule, shard_range, split_schedule
+from echoseal_amd.dist import ROW, broadcast_keys, broadcast_schedule, build_schedule, shard_range, split_schedule
 
 KEY = b"\xAA" * 32
 
@@ -40,6 +40,9 @@ def _worker(rank, world, port, n_total, out_dir):
         buf = broadcast_schedule(sched, n_total, torch.device("cpu"))
         lo, hi = shard_range(n_total, rank, world)
         pn, band = split_schedule(buf, lo, hi)
+        # the 48-byte alternative: only key material travels; each rank would expand its shard on its GPU
+        keys = broadcast_keys(bytes(range(48)) if rank == 0 else None, torch.device("cpu"))
+        assert keys == bytes(range(48))
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), pn=pn.numpy(), band=band.numpy(), lo=lo, hi=hi)
         # the data path has no collective: an all_gather here is only the test reading results back
         cnt = torch.tensor([hi - lo])

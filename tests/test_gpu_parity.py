@@ -608,3 +608,28 @@ def test_llr_shift_search_screen_is_exact(engine, oracle):
         assert obs == int(bs[i]), i
         assert np.array_equal(o, llr[i]), i
         assert np.float32(best) == sc[i, 0] and np.float32(second) == sc[i, 1], (i, best, second, sc[i])
+
+
+def test_schedule_kernel_vs_oracle(engine, oracle):
+    """es_schedule_batch (AES-128 PN rows + HMAC-SHA256 band hop on the device) == oracle == the host code behind the
+    broadcast schedule: explicit counters (including > 2^31), a contiguous range, and 2^20 counters spot-checked."""
+    from echoseal_amd.crypto import SecureChannel
+    from echoseal_amd.dist import build_schedule
+    for key in (KEY, b"\x00" * 32, bytes(range(32))):
+        sec = SecureChannel(key)
+        ctrs = [0, 1, 2, 3, 5, 255, 1024, 65535, 2 ** 31 + 5, 2 ** 32 - 1] + [int(c) for c in np.random.default_rng(9).integers(0, 2 ** 32, 300)]
+        pn, band = engine.schedule(sec._prng.sub_key, key, torch.tensor(ctrs, dtype=torch.int64))
+        wpn, wband = oracle.schedule_rows(sec._prng.sub_key, key, ctrs)
+        assert np.array_equal(pn.cpu().numpy(), wpn) and np.array_equal(band.cpu().numpy(), wband)
+    sec = SecureChannel(KEY)
+    pn, band = engine.schedule(sec._prng.sub_key, KEY, ctr0=1000, n=4097)
+    ref = build_schedule(KEY, range(1000, 1000 + 4097))
+    assert np.array_equal(pn.cpu().numpy(), ref[:, :152]) and np.array_equal(band.cpu().numpy(), ref[:, 152])
+    n = 1 << 20
+    pn, band = engine.schedule(sec._prng.sub_key, KEY, ctr0=0, n=n)
+    idx = np.random.default_rng(10).integers(0, n, 64)
+    ref = build_schedule(KEY, [int(i) for i in idx])
+    assert np.array_equal(pn[torch.from_numpy(idx).to(engine.device)].cpu().numpy(), ref[:, :152])
+    assert np.array_equal(band[torch.from_numpy(idx).to(engine.device)].cpu().numpy(), ref[:, 152])
+    with pytest.raises(ValueError):
+        engine.schedule(b"short", KEY, ctr0=0, n=4)
