@@ -280,11 +280,12 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     if (list_size > 32)
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
-    if (list_size <= 8) {
+    if (list_size <= 16) {
         // several frames per wave (es_scl_multi.hip) once the batch fills the chip with such waves: 16/L frames per
         // wave, two waves per SIMD wanted
         const long long waves = (B * list_size + 15) / 16;
-        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && waves >= (long long)ctx->num_cu * 8);
+        // (L = 16 runs on that kernel too when forced, but measures no faster than one frame per wave: auto leaves it alone)
+        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && list_size <= 8 && waves >= (long long)ctx->num_cu * 8);
         if (multi)
             return es_launch_scl_multi(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                        cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);

@@ -1,5 +1,5 @@
-// es_scl_multi.hip -- successive-cancellation LIST decoder for SHORT lists (L = 1, 2, 4, 8) with SEVERAL frames
-// per wavefront.  Same arithmetic, same bookkeeping and the same results as es_scl.hip; what changes is the
+// es_scl_multi.hip -- successive-cancellation LIST decoder for SHORT lists (L = 1, 2, 4, 8; also L = 16 as one frame
+// per wave on this kernel's smaller LDS footprint) with SEVERAL frames per wavefront.  Same arithmetic, same bookkeeping and the same results as es_scl.hip; what changes is the
 // mapping to the hardware.
 //
 // Why: with one frame per wave (es_scl.hip) a path owns P = 64/L lanes, and the bottom of the LLR tree cannot
@@ -29,13 +29,15 @@ constexpr int MGSLOT = 512 + 256 + 128 + 64;       // doubles per path slot in g
 constexpr int MROW = 72;                           // depths 5..7 at [S, 2S), S = 32, 16, 8; + 8 pad
 constexpr int MWPB = 2;                            // waves per block
 
+template <int L>
 struct MWave {
+    static constexpr bool NIB = L <= 8;            // (parent_local << 1) | bit fits a nibble up to L = 8
     double   alphaS[MNP][MROW];
     double   candm[2 * MNP];                       // frame fr: [2*L*fr, 2*L*(fr+1))
     uint32_t betaL[MNP][32];                       // left-sibling partial sums, block of S bits at bit S
     uint32_t curb[MNP][16];
     uint32_t hardw[32];
-    uint8_t  tbn[KINFO][MNP / 2];                  // trace-back nibbles: (parent_local << 1) | bit, paths 2k | 2k+1 << 4
+    uint8_t  tbn[KINFO][NIB ? MNP / 2 : MNP];      // trace-back: nibbles (paths 2k | 2k+1 << 4) or one byte per path
     uint8_t  sel[MNP];
     uint8_t  outb[MNP][56];
 };
@@ -46,10 +48,10 @@ __global__ __launch_bounds__(64 * MWPB, 2) void es_scl_multi_kernel(SclArgs a)
     constexpr int P = MP, LGP = MLGP, RD = MRD;
     constexpr int FR = MNP / L;                    // frames per wave
     constexpr int FL = 64 / FR;                    // lanes per frame
-    static_assert(L == 1 || L == 2 || L == 4 || L == 8, "short lists only");
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16, "lists of at most 16 paths");
     __shared__ __attribute__((aligned(16))) uint64_t s_exp[ES_EXP_TAB_WORDS];
     __shared__ uint16_t s_dpos[KINFO];
-    __shared__ MWave s_wave[MWPB];
+    __shared__ MWave<L> s_wave[MWPB];
 
     for (int i = threadIdx.x; i < ES_EXP_TAB_WORDS; i += blockDim.x) s_exp[i] = a.exp_tab[i];
     for (int i = threadIdx.x; i < KINFO; i += blockDim.x) s_dpos[i] = a.data_pos[i];
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(64 * MWPB, 2) void es_scl_multi_kernel(SclArgs a)
     const int fr = path / L;                       // frame within the wave
     const int pl = path % L;                       // path within the frame
     const int fp0 = fr * L;                        // first path of the frame
-    MWave& W = s_wave[wv];
+    MWave<L>& W = s_wave[wv];
     const long long wave_id = (long long)blockIdx.x * MWPB + wv;
     const long long n_waves = (long long)gridDim.x * MWPB;
     double* const scr = a.scratch + wave_id * (long long)(MNP * MGSLOT);
@@ -376,8 +378,12 @@ __global__ __launch_bounds__(64 * MWPB, 2) void es_scl_multi_kernel(SclArgs a)
                 if (!(i & 1)) lp_odd = __shfl((q & 1) ? sp_diff : sp_sum, src);
                 // trace-back nibble (parent within the frame, bit); paths 2k and 2k+1 share a byte
                 const uint32_t nib = ((uint32_t)(cc >> 1) << 1) | bit;
-                const uint32_t nib_hi = (uint32_t)__shfl((int)nib, lane + P);
-                if (q == 0 && !(path & 1)) W.tbn[info_idx][path >> 1] = (uint8_t)(nib | (nib_hi << 4));
+                if constexpr (MWave<L>::NIB) {
+                    const uint32_t nib_hi = (uint32_t)__shfl((int)nib, lane + P);
+                    if (q == 0 && !(path & 1)) W.tbn[info_idx][path >> 1] = (uint8_t)(nib | (nib_hi << 4));
+                } else {
+                    if (q == 0) W.tbn[info_idx][path] = (uint8_t)nib;
+                }
                 cnt = keep;
                 ++info_idx;
                 wave_fence_lds();
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(64 * MWPB, 2) void es_scl_multi_kernel(SclArgs a)
             uint32_t acc = 0;
             for (int tt = KINFO - 1; tt >= 0; --tt) {
                 const int gp = fp0 + cur;
-                const uint32_t c = (W.tbn[tt][gp >> 1] >> (4 * (gp & 1))) & 15u;
+                const uint32_t c = MWave<L>::NIB ? (uint32_t)((W.tbn[tt][gp >> 1] >> (4 * (gp & 1))) & 15u) : (uint32_t)W.tbn[tt][gp];
                 acc |= (c & 1u) << (7 - (tt & 7));
                 cur = (int)(c >> 1);
                 if ((tt & 7) == 0) { W.outb[path][tt >> 3] = (uint8_t)acc; acc = 0; }
@@ -465,7 +471,7 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     constexpr int FR = MNP / L;
     const long long groups = (B + FR - 1) / FR;
     long long blocks = (groups + MWPB - 1) / MWPB;
-    const long long max_blocks = (long long)ctx->num_cu * 4;    // LDS admits four blocks per CU
+    const long long max_blocks = (long long)ctx->num_cu * 4;    // LDS admits four blocks per CU (three at L = 16)
     if (blocks > max_blocks) blocks = max_blocks;
     if ((size_t)blocks * MWPB * MNP * MGSLOT * sizeof(double) > ctx->scl_scratch_bytes) {
         ctx->err = "es_scl_batch: scratch slab too small for the multi-frame kernel"; return ES_ENOMEM;
@@ -500,6 +506,7 @@ int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int 
         case 2: return launch_multi<2>(ctx, a, B, st);
         case 4: return launch_multi<4>(ctx, a, B, st);
         case 8: return launch_multi<8>(ctx, a, B, st);
-        default: ctx->err = "the multi-frame list decoder serves list sizes 1, 2, 4, 8"; return ES_EINVAL;
+        case 16: return launch_multi<16>(ctx, a, B, st);
+        default: ctx->err = "the 16-paths-per-wave list decoder serves list sizes 1, 2, 4, 8, 16"; return ES_EINVAL;
     }
 }

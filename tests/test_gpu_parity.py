@@ -550,7 +550,7 @@ def test_select_kernel_vs_oracle_and_host_rules(engine, oracle, L):
         assert len(seen) >= 3
 
 
-@pytest.mark.parametrize("L", [1, 2, 4, 8])
+@pytest.mark.parametrize("L", [1, 2, 4, 8, 16])
 def test_scl_multi_frames_per_wave(engine, oracle, L):
     """es_scl_multi.hip (16/L frames per wavefront) returns exactly what the one-frame-per-wave kernel and the oracle
     return: random LLRs, clipped LLRs (exact ties), hard-decision hits mixed in (skipped frames inside a wave), a batch

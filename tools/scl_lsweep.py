@@ -7,7 +7,7 @@ B = 16384
 llr = torch.from_numpy(np.clip(rng.normal(0, 3, (B, 1024)), -12, 12).astype(np.float32)).to(eng.device)
 for multi in (0, 1):
     eng.set_option("scl_multi", multi)
-    for L in ((1, 2, 4, 8, 16, 32) if multi == 0 else (1, 2, 4, 8)):
+    for L in ((1, 2, 4, 8, 16, 32) if multi == 0 else (1, 2, 4, 8, 16)):
         eng.scl(llr, list_size=L, skip_if_hard_ok=False); torch.cuda.synchronize()
         t0 = time.perf_counter(); eng.scl(llr, list_size=L, skip_if_hard_ok=False); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"multi={multi} L={L:2d} B={B}: {dt * 1e3:8.2f} ms -> {B / dt:10.0f} frames/s", flush=True)
