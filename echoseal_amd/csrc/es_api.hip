@@ -281,11 +281,12 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     if (list_size <= 16) {
-        // several frames per wave (es_scl_multi.hip) once the batch fills the chip with such waves: 16/L frames per
-        // wave, two waves per SIMD wanted
+        // several frames per wave (es_scl_multi.hip) once the batch yields enough such waves (16/L frames each).  One
+        // frame per wave wastes more lanes the shorter the list is, so the break-even moves down with L: measured
+        // at L = 8 it is two waves per SIMD (B = 4 096), at L = 1 a quarter of a wave per SIMD.
         const long long waves = (B * list_size + 15) / 16;
         // (L = 16 runs on that kernel too when forced, but measures no faster than one frame per wave: auto leaves it alone)
-        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && list_size <= 8 && waves >= (long long)ctx->num_cu * 8);
+        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && list_size <= 8 && waves >= (long long)ctx->num_cu * list_size);
         if (multi)
             return es_launch_scl_multi(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                        cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
