@@ -633,3 +633,27 @@ def test_schedule_kernel_vs_oracle(engine, oracle):
     assert np.array_equal(band[torch.from_numpy(idx).to(engine.device)].cpu().numpy(), ref[:, 152])
     with pytest.raises(ValueError):
         engine.schedule(b"short", KEY, ctr0=0, n=4)
+
+
+@pytest.mark.parametrize("T", [63, 64, 70, 200, 1214, 1216, 2047, 2048, 3001, 4158])
+def test_sync_fast_record_lengths(engine, T):
+    """Record lengths around every boundary of the fast path (one lag, fewer than five lags, odd / even counts, the
+    frame and window specialisations +-1, several correlation segments, the 4 096-lag maximum): thr, npeaks and peaks
+    equal the all-float64 path.  Rows mix noise, a planted frame (when it fits), a tone and a constant."""
+    rng = np.random.default_rng(T)
+    B = 24
+    x = rng.normal(0, 0.2, (B, T)).astype(np.float32)
+    frames, band, _ = _workload(B)
+    if T >= 1215:
+        for i in range(0, B, 3):
+            off = (i * 37) % (T - 1215 + 1)
+            x[i, off:off + 1215] += frames[i]
+    x[1] = np.sin(2 * np.pi * 9000 / 48000 * np.arange(T)).astype(np.float32)
+    x[2] = 0.125
+    f, b = _dev(engine, x, band)
+    ref = engine.sync(f, b, keep_corr=False)
+    fast = engine.sync_fast(f, b)
+    assert torch.equal(ref.thr, fast.thr) and torch.equal(ref.npeaks, fast.npeaks)
+    k = (ref.npeaks & 0xFFFF).clamp(max=32)
+    mask = torch.arange(32, device=engine.device)[None, :] < k[:, None]
+    assert torch.equal(ref.peaks[mask], fast.peaks[mask])
