@@ -78,6 +78,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_ws_corr) (void)hipFree(ctx->d_ws_corr);
     if (ctx->d_wide_scratch) (void)hipFree(ctx->d_wide_scratch);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
+    if (ctx->d_hdr_pn) (void)hipFree(ctx->d_hdr_pn);
     delete ctx;
 }
 
@@ -304,6 +305,22 @@ int es_schedule_batch(es_ctx* ctx, const uint8_t* aes_key16_host, const uint8_t*
     if (!aes_key16_host || !band_key32_host || !pn_rows_dev || !band_dev) return fail(ctx, ES_EINVAL, "es_schedule_batch: null pointer");
     DeviceGuard g(ctx->device);
     return es_launch_schedule(ctx, aes_key16_host, band_key32_host, ctr_dev, ctr0, n, pn_rows_dev, band_dev, (hipStream_t)stream);
+}
+
+int es_tx_frames_batch(es_ctx* ctx, const uint8_t* code_dev, const uint8_t* pn_rows_dev, const uint8_t* band_dev,
+                       const uint32_t* ctr_dev, const uint8_t* preamble8_host, const uint8_t* hdr_pn16_host, int64_t B,
+                       double* y_ws_dev, float* frames_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0) return fail(ctx, ES_EINVAL, "es_tx_frames_batch: negative batch");
+    if (B == 0) return ES_OK;
+    if (!code_dev || !pn_rows_dev || !band_dev || !ctr_dev || !preamble8_host || !hdr_pn16_host || !y_ws_dev || !frames_dev)
+        return fail(ctx, ES_EINVAL, "es_tx_frames_batch: null pointer");
+    unsigned long long pre = 0;
+    for (int i = 0; i < 8; ++i) pre = (pre << 8) | preamble8_host[i];      // 63 MLS bits, MSB first, in the top 63 bits
+    DeviceGuard g(ctx->device);
+    return es_launch_tx_frames(ctx, code_dev, pn_rows_dev, band_dev, ctr_dev, pre, hdr_pn16_host, B, y_ws_dev, frames_dev,
+                               (hipStream_t)stream);
 }
 
 int es_set_option(es_ctx* ctx, const char* name, int value)

@@ -37,6 +37,7 @@ struct es_ctx {
     double* d_ws_corr = nullptr;      size_t ws_corr_bytes = 0;
     void*   d_wide_scratch = nullptr; size_t wide_scratch_bytes = 0; int wide_slots = 0;   /* list sizes 64..256 */
     uint8_t* d_sbox = nullptr;        /* AES S-box (es_schedule_batch) */
+    uint8_t* d_hdr_pn = nullptr;      /* packed header PN (es_tx_frames_batch) */
     /* tuning (es_set_option) */
     int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
 };
@@ -81,6 +82,8 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
                   const uint8_t* band, const uint8_t* pn, int variant, float* llr, int32_t* best_s,
                   float* score, hipStream_t st);
 
+int es_launch_tx_frames(es_ctx* ctx, const uint8_t* code, const uint8_t* pn_rows, const uint8_t* band, const uint32_t* ctr,
+                        unsigned long long pre_bits, const uint8_t* hdr_pn16, int64_t B, double* y_ws, float* frames, hipStream_t st);
 int es_launch_schedule(es_ctx* ctx, const uint8_t* aes_key16, const uint8_t* band_key32, const uint32_t* ctr_dev,
                        uint32_t ctr0, int64_t n, uint8_t* pn_rows, uint8_t* band, hipStream_t st);
 int es_launch_aead_check(es_ctx* ctx, const uint8_t* key32, const uint8_t* blobs, int64_t n, int group, const uint32_t* ctr,

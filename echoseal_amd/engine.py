@@ -255,6 +255,26 @@ class RxEngine:
                   "es_schedule_batch")
         return pn, band
 
+    def make_frames(self, sec, band_key32: bytes, ctrs, payloads: torch.Tensor) -> torch.Tensor:
+        """Batch of transmitted frames on the device (WatermarkEmbedder.make_frames, rtwm/embedder.py:78-141):
+        payloads uint8 [B,55] (already sealed) under frame counters `ctrs` -> float32 [B,1215].  `sec` is the
+        SecureChannel (PN sub-key, header PN), band_key32 the hop key."""
+        from .utils import mseq_63
+        cd = self._ctr_dev(ctrs)
+        B = cd.numel()
+        payloads = self._dev(payloads, torch.uint8)
+        if payloads.shape != (B, 55):
+            raise ValueError("payloads must be uint8 [B,55], one per counter")
+        code = self.polar_encode(payloads)
+        pn, band = self.schedule(sec._prng.sub_key, band_key32, cd.to(torch.int64) & 0xFFFFFFFF)
+        pre8 = np.packbits(np.concatenate((mseq_63().astype(np.uint8), np.zeros(1, np.uint8)))).tobytes()
+        hdr16 = np.packbits(sec.pn_bits(0, 128)).tobytes()
+        y_ws = torch.empty((B, 1215), dtype=torch.float64, device=self.device)
+        frames = torch.empty((B, 1215), dtype=torch.float32, device=self.device)
+        nat.check(self._ctx, self._lib.es_tx_frames_batch(self._ctx, _ptr(code), _ptr(pn), _ptr(band), _ptr(cd), pre8, hdr16, B,
+                                                          _ptr(y_ws), _ptr(frames), self._stream()), "es_tx_frames_batch")
+        return frames
+
     # ------------------------------------------------------------------ after the list decoder (SURVEY 8 f-2)
     def _ctr_dev(self, ctrs) -> torch.Tensor:
         """Frame counters as the 32-bit words the kernels compare against (stored in an int32 tensor)."""

@@ -160,6 +160,17 @@ int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8
 int es_schedule_batch(es_ctx* ctx, const uint8_t* aes_key16_host, const uint8_t* band_key32_host, const uint32_t* ctr_dev,
                       uint32_t ctr0, int64_t n, uint8_t* pn_rows_dev, uint8_t* band_dev, void* stream);
 
+/* Frame generator: replaces WatermarkEmbedder._make_frame_chips for a batch
+ * (rtwm/embedder.py:78-141): +-1 chips = 63 preamble | 128 header (lo16(ctr) MSB first, each bit 8 times, times the
+ * header PN) | 1024 payload chips (code bit i times PN bit 191+i); band-pass of the frame's band with zero initial
+ * state; if max|chips| + 1e-12 > 3 the frame is scaled by its reciprocal; float32 out.
+ * code_dev [B][1024] {0,1} (es_polar_encode_batch), pn_rows_dev [B][152] and band_dev [B] (es_schedule_batch or the
+ * broadcast schedule), ctr_dev [B] uint32; preamble8_host = np.packbits(mseq_63()) (8 bytes, last bit unused),
+ * hdr_pn16_host = np.packbits(pn_bits(0, 128)); y_ws_dev = float64 workspace [B][1215]; frames_dev float32 [B][1215]. */
+int es_tx_frames_batch(es_ctx* ctx, const uint8_t* code_dev, const uint8_t* pn_rows_dev, const uint8_t* band_dev,
+                       const uint32_t* ctr_dev, const uint8_t* preamble8_host, const uint8_t* hdr_pn16_host, int64_t B,
+                       double* y_ws_dev, float* frames_dev, void* stream);
+
 /* Tuning knobs; results never depend on them.  "scl_multi": -1 (default) lets es_scl_batch choose between one
  * frame per wavefront and 16/L frames per wavefront (list sizes <= 8; better lane use at the bottom of the LLR
  * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.                                   */

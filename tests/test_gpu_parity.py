@@ -657,3 +657,26 @@ def test_sync_fast_record_lengths(engine, T):
     k = (ref.npeaks & 0xFFFF).clamp(max=32)
     mask = torch.arange(32, device=engine.device)[None, :] < k[:, None]
     assert torch.equal(ref.peaks[mask], fast.peaks[mask])
+
+
+def test_frame_generator_equals_host_embedder(engine):
+    """frames generated on the device (polar encode -> schedule -> chips -> band-pass -> peak rule) are
+    bit-identical to WatermarkEmbedder.make_frames (itself pinned to the reference's frames in tests/test_host_api.py),
+    for counters in every band, large counters, and both keys of the fixtures."""
+    for key in (KEY, b"\x00" * 32):
+        tx = WatermarkEmbedder(key)
+        ctrs = list(range(40)) + [255, 256, 65535, 65536, 70000, 2 ** 31 + 7, 2 ** 32 - 1]
+        payloads = synthetic_payloads(tx.sec, ctrs)
+        want = tx.make_frames(ctrs, payloads)
+        pl = torch.from_numpy(np.frombuffer(b"".join(payloads), np.uint8).reshape(len(ctrs), 55).copy())
+        got = engine.make_frames(tx.sec, key, torch.tensor(ctrs, dtype=torch.int64), pl).cpu().numpy()
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+        assert len({band_index(key, c) for c in ctrs}) == 4
+    # decode what was generated: the device-made frames go through the receive path like host-made ones
+    tx = WatermarkEmbedder(KEY); ctrs = list(range(64))
+    payloads = synthetic_payloads(tx.sec, ctrs)
+    pl = torch.from_numpy(np.frombuffer(b"".join(payloads), np.uint8).reshape(64, 55).copy())
+    frames = engine.make_frames(tx.sec, KEY, torch.tensor(ctrs), pl)
+    pn, band = engine.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=64)
+    sy, llr, scl = engine.decode_batch(frames, band, pn, list_size=8)
+    assert bool(torch.all(sy.peaks[:, 0] == 0))
