@@ -26,7 +26,7 @@ constexpr int MLGP = 2;                            // log2(MP)
 constexpr int MRD = NLEV - MLGP;                   // depths MRD..10 (sizes 4, 2, 1) live in registers
 constexpr int MGDEPTH = 4;                         // depths 1..4 live in global scratch
 constexpr int MGSLOT = 512 + 256 + 128 + 64;       // doubles per path slot in global scratch
-constexpr int MROW = 72;                           // depths 5..7 at [S, 2S), S = 32, 16, 8; + 8 pad
+constexpr int MROW = 68;                           // depths 5..7 at [S, 2S), S = 32, 16, 8; + 4 pad: a path's row starts 8 banks after its neighbour's (16 paths x 4 lanes read conflict-free)
 constexpr int MWPB = 2;                            // waves per block
 
 template <int L>
