@@ -51,7 +51,7 @@ struct WideLds {
     double   sp[2][L];                  // softplus pair of the even sibling, by slot
     uint32_t betaL[L][33];              // +1 pad: lanes hit different banks
     uint32_t curb[L][17];
-    uint16_t sel[L];
+    uint16_t sidx[2 * L];               // candidate index travelling with its metric through the sort
     uint16_t dpos[KINFO];
     uint8_t  ptrA[2][NLEV + 1][L];
     uint8_t  ptrB[2][NLEV + 1][L];
@@ -152,6 +152,15 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
                     double sd, ss;
                     dst[0] = es_polar_f_sp(pa, pb, tab, &sd, &ss);
                     W.sp[0][p] = sd; W.sp[1][p] = ss;
+                } else if (i == 0) {
+                    // first chain: every path is still a copy of path 0, so the node is computed once, the lanes
+                    // sharing its S elements, into slot 0, and every path points at it
+                    for (int j = p; j < S; j += L) {
+                        double pa, pb;
+                        if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
+                        else { pa = A[(long long)(2 * S + j) * L]; pb = A[(long long)(2 * S + j + S) * L]; }
+                        A[(long long)(S + j) * L] = es_polar_f(pa, pb, tab);
+                    }
                 } else {
                     for (int j = 0; j < S; ++j) {
                         double pa, pb;
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
                 }
                 __threadfence_block();
                 __syncthreads();
-                W.ptrA[cur][d][p] = (uint8_t)p;
+                W.ptrA[cur][d][p] = (uint8_t)((i == 0 && d != NLEV) ? 0 : p);
             }
             const double lam = A[(long long)1 * L + p];
 
@@ -184,24 +193,38 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
             } else {
                 const double m0 = metric + ((pref != 0u) ? lp + al : lp);
                 const double m1 = metric + ((pref != 1u) ? lp + al : lp);
+                // the 2*cnt candidates (path order, bit 0 then bit 1) sorted by (metric, candidate index) = Python's
+                // stable list.sort: bitonic network on (key, index) pairs in LDS, one compare-exchange per lane and
+                // stage.  Stages whose partner distance stays inside a wave's 128 elements need only a wave fence.
                 const bool live = p < cnt;
-                if (live) { W.candm[2 * p] = m0; W.candm[2 * p + 1] = m1; }
-                __syncthreads();
                 const int nc = 2 * cnt;
-                int r0 = 0, r1 = 0;
-                for (int k = 0; k < nc; ++k) {
-                    const double mk = W.candm[k];
-                    r0 += ((mk < m0) || (mk == m0 && k < 2 * p)) ? 1 : 0;
-                    r1 += ((mk < m1) || (mk == m1 && k < 2 * p + 1)) ? 1 : 0;
-                }
-                const int keep = nc < L ? nc : L;
-                if (live && r0 < keep) W.sel[r0] = (uint16_t)(2 * p);
-                if (live && r1 < keep) W.sel[r1] = (uint16_t)(2 * p + 1);
+                int nsort = 2; while (nsort < nc) nsort <<= 1;
+                W.candm[2 * p] = live ? m0 : __builtin_inf(); W.candm[2 * p + 1] = live ? m1 : __builtin_inf();
+                W.sidx[2 * p] = live ? (uint16_t)(2 * p) : (uint16_t)0xFFFF; W.sidx[2 * p + 1] = live ? (uint16_t)(2 * p + 1) : (uint16_t)0xFFFF;
                 __syncthreads();
-                const int myc = W.sel[p < keep ? p : 0];
+                for (int k = 2; k <= nsort; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        if (j >= 128) __syncthreads();
+                        if (2 * p < nsort) {
+                            const int lo = 2 * j * (p / j) + (p % j), hi = lo + j;
+                            const double ka = W.candm[lo], kb = W.candm[hi];
+                            const uint16_t ia = W.sidx[lo], ib = W.sidx[hi];
+                            const bool a_first = (ka < kb) || (ka == kb && ia < ib);
+                            const bool asc = (lo & k) == 0;
+                            if (a_first != asc) { W.candm[lo] = kb; W.candm[hi] = ka; W.sidx[lo] = ib; W.sidx[hi] = ia; }
+                        }
+                        if (j >= 128) __syncthreads();
+                        else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+                    }
+                }
+                __syncthreads();
+                const int keep = nc < L ? nc : L;
+                const int myr = p < keep ? p : 0;
+                const int myc = W.sidx[myr];
+                const double mym = W.candm[myr];
                 const int parent = myc >> 1;
                 bit = (uint32_t)(myc & 1);
-                metric = W.candm[myc];
+                metric = mym;
                 const int nxt = cur ^ 1;
                 #pragma unroll
                 for (int d = 0; d <= NLEV; ++d) {
