@@ -139,11 +139,24 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
                 const int bs = W.ptrB[cur][d][p];
                 const double* par = A + (long long)(2 * S) * L + ps;          // depth d-1 block at elements [2S, 4S)
                 double* dst = A + (long long)S * L + p;                        // depth d block at elements [S, 2S)
+                auto ld_pair = [&](int j, double& pa, double& pb) {
+                    if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
+                    else { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; }
+                };
                 if (is_g) {
-                    for (int j = 0; j < S; ++j) {
-                        double pa, pb;
-                        if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
-                        else { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; }
+                    int j = 0;
+                    for (; j + 4 <= S; j += 4) {                             // four independent load pairs in flight
+                        double pa[4], pb[4];
+                        #pragma unroll
+                        for (int u = 0; u < 4; ++u) ld_pair(j + u, pa[u], pb[u]);
+                        #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t wbits = W.betaL[bs][(S + j + u) >> 5];
+                            dst[(long long)(j + u) * L] = es_polar_g(pa[u], pb[u], (wbits >> ((S + j + u) & 31)) & 1u);
+                        }
+                    }
+                    for (; j < S; ++j) {
+                        double pa, pb; ld_pair(j, pa, pb);
                         const uint32_t wbits = W.betaL[bs][(S + j) >> 5];
                         dst[(long long)j * L] = es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u);
                     }
@@ -162,11 +175,13 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
                         A[(long long)(S + j) * L] = es_polar_f(pa, pb, tab);
                     }
                 } else {
+                    double pa, pb;                                           // operands of element j+1 are loaded while f(j) runs
+                    ld_pair(0, pa, pb);
                     for (int j = 0; j < S; ++j) {
-                        double pa, pb;
-                        if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
-                        else { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; }
+                        double na = 0.0, nb = 0.0;
+                        if (j + 1 < S) ld_pair(j + 1, na, nb);
                         dst[(long long)j * L] = es_polar_f(pa, pb, tab);
+                        pa = na; pb = nb;
                     }
                 }
                 __threadfence_block();
