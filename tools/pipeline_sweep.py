@@ -1,6 +1,6 @@
 """End-to-end (sync + LLR + SCL-8) throughput versus batch size on one GPU."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from echoseal_amd.engine import RxEngine
 from echoseal_amd.embedder import WatermarkEmbedder, synthetic_payloads
 from echoseal_amd.utils import band_index

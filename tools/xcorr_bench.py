@@ -1,7 +1,7 @@
 """Launch es_xcorr_kernel a few times on a C3-sized (65 536 x 1215) and a C2-sized (1 024) batch.
 Used under rocprofv3 (--kernel-trace --stats, or separate --pmc passes) to price the kernel."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from echoseal_amd.engine import RxEngine
 eng = RxEngine(0)
 rng = np.random.default_rng(0)
