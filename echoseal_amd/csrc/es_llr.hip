@@ -191,55 +191,73 @@ __device__ float wave_median_f32(const float* v, int n, int lane)
     return (lo + hi) / 2.0f;
 }
 
-// k-th smallest (0-based) 32-bit key among key(i), i in [0, n), by the whole 256-thread block:
-// four 8-bit-digit passes with an LDS histogram and a wave-scan prefix.  All threads return it.
+// k-th smallest 32-bit key of key(i), i in [0, n), by ONE wave: four 8-bit-digit passes on four private LDS histograms
+// (lane & 3: the leading byte of a float takes few values, and 64 lanes adding to one word would serialise), wave scan.
 template <typename F>
-__device__ uint32_t block_select_key32(int n, int k, F key, uint32_t* s_hist, uint32_t* s_pref, int* s_k)
+__device__ uint32_t wave_select_key32(uint32_t (*hist)[256], int n, int k, int lane, F key)
 {
     uint32_t prefix = 0;
     int kk = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        s_hist[threadIdx.x] = 0;
-        __syncthreads();
+        #pragma unroll
+        for (int b = 0; b < 16; ++b) (&hist[0][0])[lane + 64 * b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         const uint32_t himask = (shift == 24) ? 0u : (~0u << (shift + 8));
-        for (int i = threadIdx.x; i < n; i += LLR_THREADS) {
+        uint32_t* const myh = hist[lane & 3];
+        for (int i = lane; i < n; i += 64) {
             const uint32_t kx = key(i);
-            if ((kx & himask) == prefix) atomicAdd(&s_hist[(kx >> shift) & 255u], 1u);
+            if ((kx & himask) == prefix) atomicAdd(&myh[(kx >> shift) & 255u], 1u);
         }
-        __syncthreads();
-        {
-            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-            const uint32_t h = s_hist[threadIdx.x];
-            uint32_t incl = h;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        uint32_t h[4];
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) h[b] = hist[0][4 * lane + b] + hist[1][4 * lane + b] + hist[2][4 * lane + b] + hist[3][4 * lane + b];
+        const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
+        uint32_t incl = s4;
+        #pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        const uint32_t excl = incl - s4;
+        const bool hit = ((int)excl <= kk) && (kk < (int)incl);
+        int bin = 0, nk = 0;
+        if (hit) {
+            uint32_t c = excl;
             #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(incl, o);
-                if (lane >= o) incl += up;
+            for (int b = 0; b < 4; ++b) {
+                if (kk >= (int)c && kk < (int)(c + h[b])) { bin = 4 * lane + b; nk = kk - (int)c; }
+                c += h[b];
             }
-            __syncthreads();
-            if (lane == 63) s_hist[wv] = incl;
-            __syncthreads();
-            uint32_t basec = 0;
-            for (int w = 0; w < wv; ++w) basec += s_hist[w];
-            incl += basec;
-            const uint32_t excl = incl - h;
-            if ((int)excl <= kk && kk < (int)incl) { *s_k = kk - (int)excl; *s_pref = prefix | ((uint32_t)threadIdx.x << shift); }
         }
-        __syncthreads();
-        prefix = *s_pref;
-        kk = *s_k;
-        __syncthreads();
+        const unsigned long long m = __ballot(hit);
+        const int src = __ffsll((long long)m) - 1;
+        bin = __shfl(bin, src); kk = __shfl(nk, src);
+        prefix |= (uint32_t)bin << shift;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
     return prefix;
 }
 
+// NumPy median of val(i), i in [0, n), by one wave: one select; for even n the upper middle element comes from one
+// counting pass (it is the lower one again if enough keys are <= it, else the smallest key above it).
 template <typename F>
-__device__ float block_median_f32(int n, F val, uint32_t* s_hist, uint32_t* s_pref, int* s_k)
+__device__ float wave_median_hist_f32(uint32_t (*hist)[256], int n, int lane, F val)
 {
     auto key = [&](int i) { return f32_key(val(i)); };
-    if (n & 1) return key_f32(block_select_key32(n, n / 2, key, s_hist, s_pref, s_k));
-    const float lo = key_f32(block_select_key32(n, n / 2 - 1, key, s_hist, s_pref, s_k));
-    const float hi = key_f32(block_select_key32(n, n / 2, key, s_hist, s_pref, s_k));
+    if (n & 1) return key_f32(wave_select_key32(hist, n, n / 2, lane, key));
+    const int k_lo = n / 2 - 1, k_hi = n / 2;
+    const uint32_t key_lo = wave_select_key32(hist, n, k_lo, lane, key);
+    int le = 0; uint32_t nxt = 0xffffffffu;
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t kx = key(i);
+        le += kx <= key_lo;
+        if (kx > key_lo && kx < nxt) nxt = kx;
+    }
+    #pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        le += __shfl_xor(le, o);
+        const uint32_t on = (uint32_t)__shfl_xor((int)nxt, o);
+        nxt = on < nxt ? on : nxt;
+    }
+    const float lo = key_f32(key_lo), hi = (le > k_hi) ? lo : key_f32(nxt);
     return (lo + hi) / 2.0f;
 }
 
@@ -250,9 +268,7 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
 {
     __shared__ float s_rx[MF_PAD + MAX_RX + MF_PAD];   // zero padded both sides: no bounds in the tap loop
     __shared__ float s_h[MF_PAD];
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_pref;
-    __shared__ int s_k;
+    __shared__ uint32_t s_hist4[4][256];
     __shared__ float s_pn[NPAY];
     __shared__ float s_win[MAX_WIN];
     __shared__ float s_abs[MAX_WIN];
@@ -457,13 +473,21 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         const int toff = (n > guard + 8) ? guard : 0;
         const int nt = n - toff;
         const float* tail = s_d + toff;
-        const float medv = block_median_f32(nt, [&](int i) { return tail[i]; }, s_hist, &s_pref, &s_k);
-        const float madv = block_median_f32(nt, [&](int i) { return __builtin_fabsf(tail[i] - medv); }, s_hist, &s_pref, &s_k);
+        // wave 0: median and MAD (barrier-free selects); wave 1, at the same time: mean and variance
         if (wv == 0) {
+            const float medv = wave_median_hist_f32(s_hist4, nt, lane, [&](int i) { return tail[i]; });
+            const float madv = wave_median_hist_f32(s_hist4, nt, lane, [&](int i) { return __builtin_fabsf(tail[i] - medv); });
+            if (lane == 0) s_stats[2] = madv;
+        } else if (wv == 1) {
             PwPlan tp; pw_plan_build(tp, nt);
             const float mu = wave_pairwise_sum(tp, lane, [&](int i) { return tail[i]; }) / (float)nt;
-            const double mad = (double)madv + 1e-12;
             const float var = wave_pairwise_sum(tp, lane, [&](int i) { const float c = tail[i] - mu; return c * c; }) / (float)nt;
+            if (lane == 0) { s_stats[0] = mu; s_stats[3] = var; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float madv = s_stats[2], var = s_stats[3];
+            const double mad = (double)madv + 1e-12;
             const double sigma_mad = 1.4826 * mad;
             const double sigma_std = (double)__builtin_sqrtf(var) + 1e-12;
             double sigma = sigma_mad > sigma_std ? sigma_mad : sigma_std;
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
             double scale = 2.0 / (sigma * sigma);
             if (scale < 0.5) scale = 0.5;
             if (scale > 30.0) scale = 30.0;
-            if (lane == 0) { s_stats[0] = mu; s_stats[1] = (float)scale; }
+            s_stats[1] = (float)scale;
         }
         __syncthreads();
         const float mu = s_stats[0], scale32 = s_stats[1];
