@@ -680,3 +680,26 @@ def test_frame_generator_equals_host_embedder(engine):
     pn, band = engine.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=64)
     sy, llr, scl = engine.decode_batch(frames, band, pn, list_size=8)
     assert bool(torch.all(sy.peaks[:, 0] == 0))
+
+
+def test_decode_batch_is_graph_capturable(engine):
+    """After a warm-up call no entry point allocates or synchronises, so a whole decode_batch (band-pass, screen, exact
+    picking + redo kernels, LLR on a side stream, list decoder) can be captured into a HIP graph; the replay on new
+    input data gives what an eager call gives."""
+    frames, band, pn = _workload(128, noise=0.1, seed=5)
+    f, b, p = _dev(engine, frames, band, pn)
+    for _ in range(2):
+        engine.decode_batch(f, b, p, list_size=8)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = engine.decode_batch(f, b, p, list_size=8)
+    frames2, _, _ = _workload(128, noise=0.3, seed=6)
+    f.copy_(torch.from_numpy(frames2))                         # new samples in the captured input buffer
+    g.replay()
+    torch.cuda.synchronize()
+    ref = engine.decode_batch(f, b, p, list_size=8)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0].thr, ref[0].thr) and torch.equal(out[0].npeaks, ref[0].npeaks) and torch.equal(out[1], ref[1])
+    assert torch.equal(out[2].cand_info, ref[2].cand_info) and torch.equal(out[2].cand_metric, ref[2].cand_metric)
+    assert torch.equal(out[2].ncand, ref[2].ncand)
