@@ -266,19 +266,28 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         const uint8_t* __restrict__ pn_rows, int variant, const es_band_tables* __restrict__ tabs,
         float* __restrict__ llr, int32_t* __restrict__ best_s_out, float* __restrict__ score_out)
 {
-    __shared__ float s_rx[MF_PAD + MAX_RX + MF_PAD];   // zero padded both sides: no bounds in the tap loop
-    __shared__ float s_h[MF_PAD];
-    __shared__ uint32_t s_hist4[4][256];
+    // LDS is reused across the phases of a record (31 KB instead of 45: three blocks fit beside a resident list decoder):
+    //   region A: {s_rx, s_h} (matched filter inputs) -> s_pre (float64 prefix sums of the screen) -> s_d (despread values)
+    //   region B: s_abs (|win|, shift search) -> s_hist4 (histograms of the robust statistics)
+    constexpr int RX_N = MF_PAD + MAX_RX + MF_PAD;
+    constexpr size_t A_BYTES = (sizeof(float) * (RX_N + MF_PAD + NPAY) > sizeof(double) * (MAX_WIN + 1))
+                                   ? sizeof(float) * (RX_N + MF_PAD + NPAY) : sizeof(double) * (MAX_WIN + 1);
+    constexpr size_t B_BYTES = (sizeof(float) * MAX_WIN > sizeof(uint32_t) * 4 * 256) ? sizeof(float) * MAX_WIN : sizeof(uint32_t) * 4 * 256;
+    __shared__ __attribute__((aligned(16))) unsigned char s_regA[A_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char s_regB[B_BYTES];
+    float* const s_rx = reinterpret_cast<float*>(s_regA);             // zero padded both sides: no bounds in the tap loop
+    float* const s_h = s_rx + RX_N;
+    float* const s_d = s_h + MF_PAD;
+    double* const s_pre = reinterpret_cast<double*>(s_regA);          // float64 prefix sums of |win| (shift-search screen)
+    float* const s_abs = reinterpret_cast<float*>(s_regB);
+    uint32_t (*const s_hist4)[256] = reinterpret_cast<uint32_t (*)[256]>(s_regB);
     __shared__ float s_pn[NPAY];
     __shared__ float s_win[MAX_WIN];
-    __shared__ float s_abs[MAX_WIN];
-    __shared__ double s_pre[MAX_WIN + 1];            // float64 prefix sums of |win| (shift-search screen)
     __shared__ double s_A[2 * ES_MAX_TAPS + 8];      // exact-sum score per shift
     __shared__ int    s_cand[2 * ES_MAX_TAPS + 8];   // shifts that get the float32 NumPy-order evaluation
     __shared__ double s_wtot[4];
     __shared__ double s_top[4][2];
     __shared__ int    s_wcnt[4];
-    __shared__ float s_d[NPAY];
     __shared__ float s_score[4][2];
     __shared__ int   s_shift[4];
     __shared__ float s_stats[4];
