@@ -293,6 +293,7 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
     __shared__ float s_stats[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __builtin_amdgcn_s_setprio(2);      // front-end kernel: issue ahead of a resident list-decoder wave
 
     for (long long rec = blockIdx.x; rec < B; rec += gridDim.x) {
         float* out = llr + rec * NPAY;

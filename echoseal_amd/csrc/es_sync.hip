@@ -123,6 +123,7 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void es_bpf_quad_kernel(const void* 
     __shared__ float  s_x[BQ_WAVES][BQ_RECS][BQ_TT + 1];
     __shared__ double s_y[BQ_WAVES][BQ_RECS][BQ_TT + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __builtin_amdgcn_s_setprio(3);      // 16 records per wave and a serial recurrence: never queue behind a long-running wave
     const long long rec0 = ((long long)blockIdx.x * BQ_WAVES + wv) * BQ_RECS;
     if (rec0 >= B) return;
     const int rloc = lane >> 2, j = lane & 3;

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel
         float* __restrict__ corr)
 {
     const int T = TC ? TC : T_arg;
+    __builtin_amdgcn_s_setprio(3);      // a short kernel: when it shares a SIMD with a long-running list-decoder wave it should not queue behind it
     constexpr int SEG = 64 * R;
     constexpr int NS = SEG + ES_PRE_L - 1;
     __shared__ float s_buf[XC_WAVES][NS + 2];
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(64 * PW_WAVES) void es_pick_exact_wave_kernel(const
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
     const int n = T - (ES_PRE_L - 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __builtin_amdgcn_s_setprio(2);      // front-end kernel: issue ahead of a resident list-decoder wave
     const size_t per_wave = sizeof(PwFixed) + (((size_t)n * 4 + 15) & ~(size_t)15);
     PwFixed& S = *reinterpret_cast<PwFixed*>(pw_smem + wv * per_wave);
     float* const c = reinterpret_cast<float*>(pw_smem + wv * per_wave + sizeof(PwFixed));
