@@ -11,7 +11,8 @@
 // advance in lock step (the schedule depends on the leaf index only); a sort ranks a path against the
 // candidates of its own frame.
 //
-// LDS per wave is 17 KB (tree depths 5..7, partial sums, nibble-packed trace-back), four 2-wave blocks per CU:
+// LDS per wave is 17 KB (tree depths 5..7, partial sums, nibble-packed trace-back), two 4-wave blocks per CU (a block
+// then always covers the four SIMDs of its CU, which also lets launches from different streams share a CU evenly):
 // two waves = 2*FR frames per SIMD.  Tree depths 1..4 live in the L2-resident scratch slab, depths 8..10 in
 // registers.  Reference lines as in es_scl.hip (rtwm/fastpolar.py:254-359).
 //
@@ -27,7 +28,7 @@ constexpr int MRD = NLEV - MLGP;                   // depths MRD..10 (sizes 4, 2
 constexpr int MGDEPTH = 4;                         // depths 1..4 live in global scratch
 constexpr int MGSLOT = 512 + 256 + 128 + 64;       // doubles per path slot in global scratch
 constexpr int MROW = 68;                           // depths 5..7 at [S, 2S), S = 32, 16, 8; + 4 pad: a path's row starts 8 banks after its neighbour's (16 paths x 4 lanes read conflict-free)
-constexpr int MWPB = 2;                            // waves per block
+constexpr int MWPB = 4;                            // waves per block
 
 template <int L>
 struct MWave {
@@ -43,7 +44,7 @@ struct MWave {
 };
 
 template <int L>
-__global__ __launch_bounds__(64 * MWPB, 2) void es_scl_multi_kernel(SclArgs a)
+__global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kernel(SclArgs a)
 {
     constexpr int P = MP, LGP = MLGP, RD = MRD;
     constexpr int FR = MNP / L;                    // frames per wave
@@ -471,7 +472,7 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     constexpr int FR = MNP / L;
     const long long groups = (B + FR - 1) / FR;
     long long blocks = (groups + MWPB - 1) / MWPB;
-    const long long max_blocks = (long long)ctx->num_cu * 4;    // LDS admits four blocks per CU (three at L = 16)
+    const long long max_blocks = (long long)ctx->num_cu * 2;    // LDS admits two blocks per CU
     if (blocks > max_blocks) blocks = max_blocks;
     if ((size_t)blocks * MWPB * MNP * MGSLOT * sizeof(double) > ctx->scl_scratch_bytes) {
         ctx->err = "es_scl_batch: scratch slab too small for the multi-frame kernel"; return ES_ENOMEM;
@@ -487,7 +488,7 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
 
 size_t es_scl_multi_scratch_bytes(const es_ctx* ctx)
 {
-    return (size_t)ctx->num_cu * 4 * MWPB * MNP * MGSLOT * sizeof(double);
+    return (size_t)ctx->num_cu * 2 * MWPB * MNP * MGSLOT * sizeof(double);
 }
 
 int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
