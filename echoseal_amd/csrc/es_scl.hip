@@ -399,7 +399,18 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
                 constexpr int G = (P >= 2) ? P / 2 : 1;              // lanes sharing one candidate
                 constexpr int SPAN = (2 * L + G - 1) / G;            // candidates each of them compares against
                 const int cb = q & 1;
-                const double mc = __shfl(m, path * P + cb);          // metric of candidate 2*path + cb
+                double mc;                                           // metric of candidate 2*path + cb
+                if constexpr (P == 8) {
+                    // lane (path, q) wants lane (path, q & 1): inside a quad quad_perm [0,1,0,1]; the upper quad of the
+                    // path then takes the lower quad's copy (row_shr:4) -- DPP moves instead of an LDS-pipe permute
+                    uint64_t u; __builtin_memcpy(&u, &m, 8);
+                    int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+                    lo = __builtin_amdgcn_mov_dpp(lo, 0x44, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x44, 0xf, 0xf, true);
+                    const int lo2 = __builtin_amdgcn_mov_dpp(lo, 0x114, 0xf, 0xf, true), hi2 = __builtin_amdgcn_mov_dpp(hi, 0x114, 0xf, 0xf, true);
+                    if (q & 4) { lo = lo2; hi = hi2; }
+                    u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+                    __builtin_memcpy(&mc, &u, 8);
+                } else mc = __shfl(m, path * P + cb);
                 const int cc_ = 2 * path + cb;
                 const int k0 = (q >> 1) * SPAN;
                 int rank = 0;
@@ -409,8 +420,11 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
                     const double mk = W.candm[k < 2 * L ? k : 0];
                     rank += ((k < nc) && ((mk < mc) || (mk == mc && k < cc_))) ? 1 : 0;
                 }
-                #pragma unroll
-                for (int o = 2; o < P; o <<= 1) rank += __shfl_xor(rank, o);
+                if constexpr (P >= 4) rank += xor_lanes_b32<2>(rank, lane);
+                if constexpr (P >= 8) rank += xor_lanes_b32<4>(rank, lane);
+                if constexpr (P >= 16) rank += xor_lanes_b32<8>(rank, lane);
+                if constexpr (P >= 32) rank += xor_lanes_b32<16>(rank, lane);
+                if constexpr (P >= 64) rank += xor_lanes_b32<32>(rank, lane);
                 ES_STAMP(t_s2);
                 const int keep = nc < L ? nc : L;
                 // new path r continues the candidate of rank r; `src` = lane holding that candidate

@@ -350,7 +350,14 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
                 constexpr int G = P / 2;                             // lanes sharing one candidate
                 constexpr int SPAN = (2 * L + G - 1) / G;            // candidates each of them compares against
                 const int cb = q & 1;
-                const double mc = __shfl(m, path * P + cb);          // metric of candidate 2*pl + cb
+                double mc;                                           // metric of candidate 2*pl + cb: lane (path, q & 1)
+                {
+                    uint64_t u; __builtin_memcpy(&u, &m, 8);
+                    const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)u, 0x44, 0xf, 0xf, true);          // quad_perm [0,1,0,1]
+                    const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), 0x44, 0xf, 0xf, true);
+                    u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+                    __builtin_memcpy(&mc, &u, 8);
+                }
                 const int cc_ = 2 * pl + cb;
                 const int kk0 = (q >> 1) * SPAN;
                 int rank = 0;
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
                     const double mk = W.candm[2 * fp0 + (k < 2 * L ? k : 0)];
                     rank += ((k < nc) && ((mk < mc) || (mk == mc && k < cc_))) ? 1 : 0;
                 }
-                rank += __shfl_xor(rank, 2);
+                rank += xor_lanes_b32<2>(rank, lane);
                 const int keep = nc < L ? nc : L;
                 if (is_cand && rank < keep) W.sel[fp0 + rank] = (uint8_t)cl;
                 wave_fence_lds();
