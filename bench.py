@@ -76,8 +76,8 @@ def cpu_baseline(frames, band, pn, L, budget_s=15.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frame records per GPU per step (C2 = 1024)")
     ap.add_argument("--list-size", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
