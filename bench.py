@@ -81,6 +81,7 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=1024, help="frame records per GPU per step (C2 = 1024)")
     ap.add_argument("--list-size", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--scl-streams", type=int, default=2, help="list-decoder streams (= batches in flight) of the pipeline")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: = --scl-streams)")
     ap.add_argument("--scl-multi", type=int, default=-1, help="es_set_option scl_multi: -1 auto, 0 one frame per wave, 1 several")
@@ -91,11 +92,16 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from echoseal_amd.dist import broadcast_schedule, build_schedule, shard_range, split_schedule
     from echoseal_amd.embedder import WatermarkEmbedder, synthetic_payloads
