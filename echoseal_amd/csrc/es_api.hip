@@ -323,6 +323,19 @@ int es_tx_frames_batch(es_ctx* ctx, const uint8_t* code_dev, const uint8_t* pn_r
                                (hipStream_t)stream);
 }
 
+int es_resample_batch(es_ctx* ctx, const void* x_dev, int dtype, int64_t B, int64_t n_in, const void* h_tf_dev, int h_per_phase,
+                      int up, int down, int64_t y0, int64_t n_out, void* out_dev, void* stream)
+{
+    if (!ctx) return ES_EINVAL;
+    if (B < 0 || n_in < 0 || n_out < 0) return fail(ctx, ES_EINVAL, "es_resample_batch: negative size");
+    if (dtype != ES_DTYPE_F32 && dtype != ES_DTYPE_F64) return fail(ctx, ES_EINVAL, "es_resample_batch: dtype must be f32 or f64");
+    if (up < 1 || down < 1 || h_per_phase < 1 || y0 < 0) return fail(ctx, ES_EINVAL, "es_resample_batch: bad rate / filter geometry");
+    if (B == 0 || n_out == 0) return ES_OK;
+    if (!x_dev || !h_tf_dev || !out_dev) return fail(ctx, ES_EINVAL, "es_resample_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_resample(ctx, x_dev, dtype, B, n_in, h_tf_dev, h_per_phase, up, down, y0, n_out, out_dev, (hipStream_t)stream);
+}
+
 int es_set_option(es_ctx* ctx, const char* name, int value)
 {
     if (!ctx || !name) return ES_EINVAL;

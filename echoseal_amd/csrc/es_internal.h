@@ -84,6 +84,8 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
 
 int es_launch_tx_frames(es_ctx* ctx, const uint8_t* code, const uint8_t* pn_rows, const uint8_t* band, const uint32_t* ctr,
                         unsigned long long pre_bits, const uint8_t* hdr_pn16, int64_t B, double* y_ws, float* frames, hipStream_t st);
+int es_launch_resample(es_ctx* ctx, const void* x, int dtype, int64_t B, int64_t n_x, const void* h_tf, int hpp, int up, int down,
+                       int64_t y0, int64_t n_out, void* out, hipStream_t st);
 int es_launch_schedule(es_ctx* ctx, const uint8_t* aes_key16, const uint8_t* band_key32, const uint32_t* ctr_dev,
                        uint32_t ctr0, int64_t n, uint8_t* pn_rows, uint8_t* band, hipStream_t st);
 int es_launch_aead_check(es_ctx* ctx, const uint8_t* key32, const uint8_t* blobs, int64_t n, int group, const uint32_t* ctr,

@@ -73,7 +73,12 @@ class WatermarkDetector:
 
     # ------------------------------------------------------------------ API
     def verify(self, audio: np.ndarray, fs_in: int) -> bool:
-        signal, _ = resample_to(self.fs_target, np.asarray(audio), fs_in)
+        audio = np.asarray(audio)
+        if fs_in != self.fs_target and audio.ndim == 1 and audio.size:
+            # polyphase resampling on the device (es_resample_batch): the values scipy.signal.resample_poly returns
+            signal = self.engine.resample(audio, fs_in, self.fs_target).cpu().numpy()
+        else:
+            signal, _ = resample_to(self.fs_target, audio, fs_in)
         hop0 = choose_band(self._band_key, 0)
         if self._scan_band_multi_frame(signal, hop0):
             return True

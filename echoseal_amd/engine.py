@@ -235,6 +235,31 @@ class RxEngine:
                   "es_polar_encode_batch")
         return code
 
+    # ------------------------------------------------------------------ input conditioning
+    def resample(self, audio, fs_orig: int, fs_target: int) -> torch.Tensor:
+        """resample_to (rtwm/utils.py:58-66) on the device: 1-D or [B,n] signal -> the same values
+        scipy.signal.resample_poly(audio, fs_target/g, fs_orig/g) returns (float32 for float32 input, else float64),
+        bit for bit.  Equal rates return the input as a device tensor."""
+        from .utils import resample_plan
+        x = audio if torch.is_tensor(audio) else torch.as_tensor(np.asarray(audio))
+        one_d = x.dim() == 1
+        if one_d:
+            x = x.reshape(1, -1)
+        np_dtype = np.dtype(str(x.dtype).replace("torch.", ""))
+        plan = resample_plan(x.shape[1], fs_target, fs_orig, np_dtype)
+        if plan is None:
+            out = x.to(self.device)
+            return out[0] if one_d else out
+        h_tf, hpp, up, down, y0, n_out, ctype = plan
+        tdt = torch.float32 if ctype == np.float32 else torch.float64
+        xd = self._dev(x, tdt)
+        hd = torch.from_numpy(h_tf).to(self.device)
+        out = torch.empty((x.shape[0], n_out), dtype=tdt, device=self.device)
+        nat.check(self._ctx, self._lib.es_resample_batch(self._ctx, _ptr(xd), nat.ES_DTYPE_F32 if tdt == torch.float32 else nat.ES_DTYPE_F64,
+                                                         x.shape[0], x.shape[1], _ptr(hd), hpp, up, down, y0, n_out, _ptr(out),
+                                                         self._stream()), "es_resample_batch")
+        return out[0] if one_d else out
+
     # ------------------------------------------------------------------ key / PN / hop schedule (SURVEY 8 a18, f-3)
     def schedule(self, aes_key16: bytes, band_key32: bytes, ctrs=None, *, ctr0: int = 0, n: int | None = None):
         """PN rows and band indices of frame counters, derived on the device: -> (pn [n,152] uint8, band [n] uint8).

@@ -56,6 +56,43 @@ def resample_to(fs_target: int, audio: np.ndarray, fs_orig: int) -> tuple[np.nda
     return resample_poly(audio, fs_target // g, fs_orig // g), fs_target
 
 
+def resample_plan(n_in: int, up: int, down: int, dtype):
+    """Everything scipy.signal.resample_poly(x, up, down) does in Python before its compiled loop (SciPy 1.15: Kaiser-5.0
+    `firwin` design of 20*max(up,down)+1 taps scaled by `up`, zero padding that centres the output, the kept output
+    range) plus upfirdn's transposed / flipped polyphase layout.  -> (h_tf, taps per phase, up, down, first kept output,
+    number of outputs, compute dtype), or None when the rates are equal.  The loop itself is es_resample_batch."""
+    from scipy.signal import firwin
+    g = math.gcd(int(up), int(down))
+    up, down = int(up) // g, int(down) // g
+    if up == down == 1:
+        return None
+    n_out = n_in * up
+    n_out = n_out // down + bool(n_out % down)
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0))
+    if np.issubdtype(np.dtype(dtype), np.floating):
+        h = h.astype(dtype)
+    h *= up
+    n_pre_pad = down - half_len % down
+    n_post_pad = 0
+    n_pre_remove = (half_len + n_pre_pad) // down
+
+    def _output_len(len_h: int) -> int:
+        nt = (n_in + (len_h + (-len_h % up)) // up - 1) * up
+        return nt // down + (1 if nt % down > 0 else 0)
+
+    while _output_len(len(h) + n_pre_pad + n_post_pad) < n_out + n_pre_remove:
+        n_post_pad += 1
+    h = np.concatenate((np.zeros(n_pre_pad, h.dtype), h, np.zeros(n_post_pad, h.dtype)))
+    ctype = np.result_type(h.dtype, np.dtype(dtype), np.float32)
+    padlen = len(h) + (-len(h) % up)
+    hf = np.zeros(padlen, ctype)
+    hf[: len(h)] = h
+    h_tf = np.ascontiguousarray(hf.reshape(-1, up).T[:, ::-1].ravel())
+    return h_tf, padlen // up, up, down, n_pre_remove, n_out, np.dtype(ctype)
+
+
 class StreamPRNG:
     """AES-128 block stream: block j of frame c is AES(sub_key, (c << 64 | j) big-endian)."""
 

@@ -171,6 +171,15 @@ int es_tx_frames_batch(es_ctx* ctx, const uint8_t* code_dev, const uint8_t* pn_r
                        const uint32_t* ctr_dev, const uint8_t* preamble8_host, const uint8_t* hdr_pn16_host, int64_t B,
                        double* y_ws_dev, float* frames_dev, void* stream);
 
+/* Input conditioning: the polyphase FIR inside resample_to (rtwm/utils.py:58-66 =
+ * scipy.signal.resample_poly(audio, up, down) -> upfirdn, zero extension).  The caller designs the filter exactly as
+ * SciPy does (firwin, Kaiser 5.0, scaled by `up`, padded) and passes it in SciPy's transposed / flipped polyphase layout
+ * (h_tf_dev, `up` phases of h_per_phase taps, element type = dtype); x_dev [B][n_in] and out_dev [B][n_out] have the same
+ * element type (ES_DTYPE_F32 for float32 signals, ES_DTYPE_F64 otherwise: SciPy's output type).  Output k of a row is
+ * sample y0 + k of the full upfirdn result (y0 = SciPy's n_pre_remove).  Bit-identical to SciPy 1.15's compiled loop. */
+int es_resample_batch(es_ctx* ctx, const void* x_dev, int dtype, int64_t B, int64_t n_in, const void* h_tf_dev, int h_per_phase,
+                      int up, int down, int64_t y0, int64_t n_out, void* out_dev, void* stream);
+
 /* Tuning knobs; results never depend on them.  "scl_multi": -1 (default) lets es_scl_batch choose between one
  * frame per wavefront and 16/L frames per wavefront (list sizes <= 8; better lane use at the bottom of the LLR
  * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.                                   */

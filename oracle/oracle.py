@@ -198,3 +198,48 @@ def schedule_rows(aes_key: bytes, band_key: bytes, ctrs):
     for i, c in enumerate(ctrs):
         lib().eso_schedule_row(_p(ak), _p(bk), ctypes.c_uint32(int(c)), _p(pn[i]), _p(b1)); band[i] = b1[0]
     return pn, band
+
+
+# ------------------------------------------------------------------------------- input conditioning (f-4)
+def resample_plan(n_in: int, up: int, down: int, dtype):
+    """SciPy's resample_poly set-up (Python in SciPy: filter design, padding, kept range), restated call for call:
+    -> (h_trans_flip, h_per_phase, up, down, n_pre_remove, n_out, compute dtype) or None when up == down."""
+    import math
+    from scipy.signal import firwin
+    g = math.gcd(int(up), int(down)); up = int(up) // g; down = int(down) // g
+    if up == down == 1:
+        return None
+    n_out = n_in * up; n_out = n_out // down + bool(n_out % down)
+    max_rate = max(up, down); half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0))
+    if np.issubdtype(np.dtype(dtype), np.floating):
+        h = h.astype(dtype)
+    h *= up
+    n_pre_pad = down - half_len % down; n_post_pad = 0; n_pre_remove = (half_len + n_pre_pad) // down
+    def out_len(len_h):                                   # scipy.signal._upfirdn._output_len
+        in_len_copy = n_in + (len_h + (-len_h % up)) // up - 1
+        nt = in_len_copy * up
+        need = nt // down + (1 if nt % down > 0 else 0)
+        return need
+    while out_len(len(h) + n_pre_pad + n_post_pad) < n_out + n_pre_remove:
+        n_post_pad += 1
+    h = np.concatenate((np.zeros(n_pre_pad, h.dtype), h, np.zeros(n_post_pad, h.dtype)))
+    ctype = np.result_type(h.dtype, np.dtype(dtype), np.float32)
+    h = np.asarray(h, ctype)
+    padlen = len(h) + (-len(h) % up)
+    hf = np.zeros(padlen, ctype); hf[:len(h)] = h
+    h_tf = np.ascontiguousarray(hf.reshape(-1, up).T[:, ::-1].ravel())
+    return h_tf, padlen // up, up, down, n_pre_remove, n_out, ctype
+
+def resample_poly(x, up: int, down: int):
+    """scipy.signal.resample_poly(x, up, down) for a 1-D signal through the C restatement of upfirdn's inner loop."""
+    x = np.asarray(x)
+    plan = resample_plan(x.shape[0], up, down, x.dtype)
+    if plan is None:
+        return x.copy()
+    h_tf, hpp, up, down, y0, n_out, ctype = plan
+    xc = _c(x, ctype); out = np.zeros(n_out, ctype)
+    fn = lib().eso_upfirdn_f32 if ctype == np.float32 else lib().eso_upfirdn_f64
+    fn(_p(xc), ctypes.c_long(xc.size), _p(h_tf), ctypes.c_long(hpp), ctypes.c_long(up), ctypes.c_long(down),
+       ctypes.c_long(y0), ctypes.c_long(n_out), _p(out))
+    return out

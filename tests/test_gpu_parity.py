@@ -703,3 +703,25 @@ def test_decode_batch_is_graph_capturable(engine):
     assert torch.equal(out[0].thr, ref[0].thr) and torch.equal(out[0].npeaks, ref[0].npeaks) and torch.equal(out[1], ref[1])
     assert torch.equal(out[2].cand_info, ref[2].cand_info) and torch.equal(out[2].cand_metric, ref[2].cand_metric)
     assert torch.equal(out[2].ncand, ref[2].ncand)
+
+
+@pytest.mark.parametrize("fs_in", [44100, 22050, 96000, 47999, 8000])
+def test_resample_kernel_equals_scipy(engine, oracle, fs_in):
+    """es_resample_batch returns scipy.signal.resample_poly's values bit for bit (float32, float64 and
+    int16 signals; single clip and batch), i.e. what the reference's resample_to hands to the detector."""
+    from scipy.signal import resample_poly
+    import math
+    rng = np.random.default_rng(fs_in)
+    g = math.gcd(fs_in, 48000); up, down = 48000 // g, fs_in // g
+    for dtype in (np.float32, np.float64, np.int16):
+        n = int(rng.integers(2000, 30000))
+        x = rng.normal(0, 0.3, n)
+        x = (x * 20000).astype(np.int16) if dtype == np.int16 else x.astype(dtype)
+        ref = resample_poly(x, up, down)
+        got = engine.resample(x, fs_in, 48000).cpu().numpy()
+        assert got.dtype == ref.dtype and got.shape == ref.shape and np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        assert np.array_equal(oracle.resample_poly(x, up, down).view(np.uint8), ref.view(np.uint8))
+    xb = rng.normal(0, 0.2, (5, 4000)).astype(np.float32)
+    gb = engine.resample(xb, fs_in, 48000).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(gb[i].view(np.uint8), resample_poly(xb[i], up, down).view(np.uint8))
