@@ -52,6 +52,7 @@ SIGNATURES = {
     "es_resample_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "es_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "es_aead_check_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "es_aead_seal_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "es_select_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -140,6 +140,43 @@ __device__ bool validate_blob(const AeadKey& key, const uint8_t* __restrict__ bl
     return tag_ok && pt[0] == 0x4c415345u /* "ESAL" little endian */ && be_ctr == ctr;
 }
 
+// SecureChannel.seal (rtwm/crypto.py:33-37): blob = nonce 12 | ChaCha20(counter 1) xor plaintext 27 | Poly1305 tag 16
+__global__ __launch_bounds__(256) void es_aead_seal_kernel(AeadKey key, const uint8_t* __restrict__ nonces,
+        const uint8_t* __restrict__ plain, long long n, uint8_t* __restrict__ blobs)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint8_t* nb = nonces + i * 12;
+        const uint8_t* pb = plain + i * 27;
+        uint32_t nonce[3], pt[8];
+        #pragma unroll
+        for (int w = 0; w < 3; ++w) nonce[w] = (uint32_t)nb[4 * w] | ((uint32_t)nb[4 * w + 1] << 8) | ((uint32_t)nb[4 * w + 2] << 16) | ((uint32_t)nb[4 * w + 3] << 24);
+        #pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t v = 0;
+            #pragma unroll
+            for (int b = 0; b < 4; ++b) { const int o = 4 * w + b; if (o < 27) v |= (uint32_t)pb[o] << (8 * b); }
+            pt[w] = v;
+        }
+        uint32_t ks[16], ct[8];
+        chacha20_block(key, 1, nonce, ks);
+        #pragma unroll
+        for (int w = 0; w < 7; ++w) ct[w] = pt[w] ^ ks[w];
+        ct[6] &= 0x00ffffffu; ct[7] = 0;
+        chacha20_block(key, 0, nonce, ks);
+        Poly P; P.init(ks);
+        P.block(ct); P.block(ct + 4);
+        const uint32_t lens[4] = {0u, 0u, 27u, 0u};
+        P.block(lens);
+        uint32_t tag[4];
+        P.finish(ks, tag);
+        uint8_t* out = blobs + i * ES_INFO_BYTES;
+        for (int b = 0; b < 12; ++b) out[b] = nb[b];
+        for (int b = 0; b < 27; ++b) out[12 + b] = (uint8_t)(ct[b >> 2] >> (8 * (b & 3)));
+        for (int b = 0; b < 16; ++b) out[39 + b] = (uint8_t)(tag[b >> 2] >> (8 * (b & 3)));
+    }
+}
+
 __global__ __launch_bounds__(256) void es_aead_check_kernel(AeadKey key, const uint8_t* __restrict__ blobs, long long n,
         int group, const uint32_t* __restrict__ ctr, uint8_t* __restrict__ ok, uint8_t* __restrict__ plain)
 {
@@ -203,6 +240,17 @@ int es_launch_aead_check(es_ctx* ctx, const uint8_t* key32, const uint8_t* blobs
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(es_aead_check_kernel, dim3((unsigned)blocks), dim3(256), 0, st, load_key(key32), blobs, (long long)n,
                        group, ctr, ok, plain);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}
+
+int es_launch_aead_seal(es_ctx* ctx, const uint8_t* key32, const uint8_t* nonces, const uint8_t* plain, int64_t n, uint8_t* blobs,
+                        hipStream_t st)
+{
+    long long blocks = (n + 255) / 256;
+    const long long cap = (long long)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(es_aead_seal_kernel, dim3((unsigned)blocks), dim3(256), 0, st, load_key(key32), nonces, plain, (long long)n, blobs);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }

@@ -368,6 +368,17 @@ int es_aead_check_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* b
     return es_launch_aead_check(ctx, key32_host, blobs_dev, n, group, ctr_dev, ok_dev, plain_dev, (hipStream_t)stream);
 }
 
+int es_aead_seal_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* nonces_dev, const uint8_t* plain_dev, int64_t n,
+                       uint8_t* blobs_dev, void* stream)
+{
+    if (!ctx) return ES_EINVAL;
+    if (n < 0) return fail(ctx, ES_EINVAL, "es_aead_seal_batch: negative count");
+    if (n == 0) return ES_OK;
+    if (!key32_host || !nonces_dev || !plain_dev || !blobs_dev) return fail(ctx, ES_EINVAL, "es_aead_seal_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_aead_seal(ctx, key32_host, nonces_dev, plain_dev, n, blobs_dev, (hipStream_t)stream);
+}
+
 int es_select_batch(es_ctx* ctx, const uint8_t* key32_host, const uint32_t* ctr_dev, int64_t B, int L,
                     const uint8_t* hard_info_dev, const uint8_t* hard_ok_dev, const uint8_t* cand_info_dev,
                     const double* cand_metric_dev, const uint8_t* cand_ok_dev, const int32_t* ncand_dev,

@@ -88,6 +88,8 @@ int es_launch_resample(es_ctx* ctx, const void* x, int dtype, int64_t B, int64_t
                        int64_t y0, int64_t n_out, void* out, hipStream_t st);
 int es_launch_schedule(es_ctx* ctx, const uint8_t* aes_key16, const uint8_t* band_key32, const uint32_t* ctr_dev,
                        uint32_t ctr0, int64_t n, uint8_t* pn_rows, uint8_t* band, hipStream_t st);
+int es_launch_aead_seal(es_ctx* ctx, const uint8_t* key32, const uint8_t* nonces, const uint8_t* plain, int64_t n, uint8_t* blobs,
+                        hipStream_t st);
 int es_launch_aead_check(es_ctx* ctx, const uint8_t* key32, const uint8_t* blobs, int64_t n, int group, const uint32_t* ctr,
                          uint8_t* ok, uint8_t* plain, hipStream_t st);
 int es_launch_select(es_ctx* ctx, const uint8_t* key32, const uint32_t* ctr, int64_t B, int L, const uint8_t* hard_info,

@@ -325,6 +325,19 @@ class RxEngine:
                                                            _ptr(plain), self._stream()), "es_aead_check_batch")
         return (ok, plain) if want_plain else ok
 
+    def aead_seal(self, key32: bytes, nonces: torch.Tensor, plain: torch.Tensor) -> torch.Tensor:
+        """SecureChannel.seal for a batch of 27-byte plaintexts (rtwm/crypto.py:33-37): nonces uint8 [n,12],
+        plain uint8 [n,27] -> blobs uint8 [n,55] on the device."""
+        if len(key32) != 32:
+            raise ValueError("AEAD key must be 32 bytes")
+        nonces = self._dev(nonces, torch.uint8); plain = self._dev(plain, torch.uint8)
+        if nonces.dim() != 2 or nonces.shape[1] != 12 or plain.shape != (nonces.shape[0], 27):
+            raise ValueError("nonces must be [n,12] and plain [n,27]")
+        blobs = torch.empty((nonces.shape[0], 55), dtype=torch.uint8, device=self.device)
+        nat.check(self._ctx, self._lib.es_aead_seal_batch(self._ctx, bytes(key32), _ptr(nonces), _ptr(plain), nonces.shape[0],
+                                                          _ptr(blobs), self._stream()), "es_aead_seal_batch")
+        return blobs
+
     def select(self, scl: SclResult, *, key32: bytes | None = None, ctrs: torch.Tensor | None = None):
         """Tail of PolarCode.decode (rtwm/fastpolar.py:268-276, 332-359) for every record of an SclResult, on the
         GPU: -> (payload [B,55] uint8, ok [B] int8, which [B] int32).  key32=None is validator=None; with a key the

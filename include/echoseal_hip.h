@@ -195,6 +195,12 @@ int es_set_option(es_ctx* ctx, const char* name, int value);
 int es_aead_check_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* blobs_dev, int64_t n, int group,
                         const uint32_t* ctr_dev, uint8_t* ok_dev, uint8_t* plain_dev, void* stream);
 
+/* The producer side of the same AEAD: SecureChannel.seal (rtwm/crypto.py:33-37) for 27-byte plaintexts with given
+ * nonces: blobs_dev [n][55] = nonce 12 | ciphertext 27 | tag 16 (what the embedder puts into a frame, rtwm/embedder.py:153-168).
+ * nonces_dev [n][12], plain_dev [n][27].                                                                            */
+int es_aead_seal_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* nonces_dev, const uint8_t* plain_dev, int64_t n,
+                       uint8_t* blobs_dev, void* stream);
+
 /* Candidate selection: replaces the tail of PolarCode.decode (rtwm/fastpolar.py:268-276, 332-359) over the outputs
  * of es_scl_batch: the hard candidate if its CRC holds and the validator accepts it; else the first list candidate
  * (ascending metric) whose CRC holds and which the validator accepts (ok = 1); else the lowest-metric CRC-ok

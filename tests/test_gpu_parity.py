@@ -725,3 +725,25 @@ def test_resample_kernel_equals_scipy(engine, oracle, fs_in):
     gb = engine.resample(xb, fs_in, 48000).cpu().numpy()
     for i in range(5):
         assert np.array_equal(gb[i].view(np.uint8), resample_poly(xb[i], up, down).view(np.uint8))
+
+
+def test_aead_seal_kernel(engine, oracle):
+    """es_aead_seal_batch == SecureChannel.seal (host, RFC 8439-pinned) for random plaintexts and nonces; and what it
+    seals opens with the device validator and with the oracle."""
+    from echoseal_amd.crypto import SecureChannel
+    rng = np.random.default_rng(77)
+    sec = SecureChannel(KEY); key = sec._aead._key
+    n = 2048
+    ctrs = rng.integers(0, 2 ** 32, n)
+    plain = np.zeros((n, 27), np.uint8)
+    plain[:, :4] = np.frombuffer(b"ESAL", np.uint8)
+    plain[:, 4:8] = ctrs.astype(">u4").view(np.uint8).reshape(n, 4)
+    plain[:, 8:] = rng.integers(0, 256, (n, 19), dtype=np.uint8)
+    nonces = rng.integers(0, 256, (n, 12), dtype=np.uint8)
+    blobs = engine.aead_seal(key, torch.from_numpy(nonces), torch.from_numpy(plain)).cpu().numpy()
+    for i in range(0, n, 97):
+        assert blobs[i].tobytes() == sec.seal(plain[i].tobytes(), nonce=nonces[i].tobytes())
+    ok, pt = engine.aead_check(key, torch.from_numpy(blobs).to(engine.device), torch.from_numpy(ctrs.astype(np.int64)), want_plain=True)
+    assert bool(torch.all(ok == 1)) and np.array_equal(pt.cpu().numpy(), plain)
+    wok, wpt = oracle.validate_blobs(key, blobs[:64], ctrs[:64])
+    assert wok.all() and np.array_equal(wpt, plain[:64])
