@@ -161,36 +161,6 @@ __device__ __forceinline__ float key_f32(uint32_t k)
     float x; __builtin_memcpy(&x, &b, 4); return x;
 }
 
-// k-th smallest of v[0..n) by one wave: bitwise radix select with ballot popcounts.
-__device__ float wave_select_f32(const float* v, int n, int k, int lane)
-{
-    uint32_t prefix = 0;
-    int kk = k;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t himask = (bit == 31) ? 0u : (~0u << (bit + 1));
-        int zeros = 0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            bool z = false;
-            if (i < n) {
-                const uint32_t key = f32_key(v[i]);
-                z = ((key & himask) == prefix) && !((key >> bit) & 1u);
-            }
-            zeros += __popcll(__ballot(z));
-        }
-        if (kk >= zeros) { kk -= zeros; prefix |= (1u << bit); }
-    }
-    return key_f32(prefix);
-}
-
-__device__ float wave_median_f32(const float* v, int n, int lane)
-{
-    if (n & 1) return wave_select_f32(v, n, n / 2, lane);
-    const float lo = wave_select_f32(v, n, n / 2 - 1, lane);
-    const float hi = wave_select_f32(v, n, n / 2, lane);
-    return (lo + hi) / 2.0f;
-}
-
 // k-th smallest 32-bit key of key(i), i in [0, n), by ONE wave: four 8-bit-digit passes on four private LDS histograms
 // (lane & 3: the leading byte of a float takes few values, and 64 lanes adding to one word would serialise), wave scan.
 template <typename F>

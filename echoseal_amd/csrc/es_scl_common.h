@@ -42,15 +42,6 @@ __device__ __forceinline__ uint64_t ptr_set(uint64_t p, int depth, int slot)
 }
 __device__ __forceinline__ int ptr_get(uint64_t p, int depth) { return (int)((p >> (6 * (depth - 1))) & 63ULL); }
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane)
-{
-    uint64_t u; __builtin_memcpy(&u, &v, 8);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src_lane);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src_lane);
-    u = ((uint64_t)hi << 32) | lo;
-    double r; __builtin_memcpy(&r, &u, 8); return r;
-}
-
 // lane l <-> lane l ^ S for a compile-time S, through DPP where the data-parallel primitives reach
 // (S = 1, 2: quad_perm; S = 4, 8: a row shift each way and a select); otherwise ds_bpermute.
 template <int S>
