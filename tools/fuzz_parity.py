@@ -9,6 +9,10 @@ from echoseal_amd.tables import pack_tables
 orc.build()
 eng = RxEngine(0, list_size_max=32); dev = eng.device
 ba, tpl, taps, ntaps, _ = pack_tables()
+from echoseal_amd.embedder import WatermarkEmbedder, synthetic_payloads
+from echoseal_amd.utils import band_index
+_KEY = b"\xAA" * 32; _tx = WatermarkEmbedder(_KEY); _c = list(range(32))
+FR = _tx.make_frames(_c, synthetic_payloads(_tx.sec, _c)); FR_BAND = [band_index(_KEY, c) for c in _c]
 bad = 0
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     rng = np.random.default_rng(1000 + seed)
@@ -37,6 +41,14 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     r[2::11] = np.round(r[2::11] * 4) / 4
     r[3::13] = np.tile(r[3::13, :97], (1, T // 97 + 1))[:, :T]
     band = rng.integers(0, 4, n).astype(np.uint8)
+    # planted frames of random strength (peaks anywhere between the noise floor and the 0.95 cap; sometimes two of them,
+    # closer than the 607-lag exclusion zone or further apart)
+    for i in range(4, n, 3):
+        band[i] = FR_BAND[i % len(FR_BAND)]
+        amp = 10.0 ** rng.uniform(-1.5, 0.7)
+        for rep in range(int(rng.integers(1, 3))):
+            off = int(rng.integers(0, T - 1215 + 1))
+            r[i, off:off + 1215] += (amp * FR[i % len(FR)]).astype(np.float32)
     f = torch.from_numpy(r).to(dev); bb = torch.from_numpy(band).to(dev)
     ref = eng.sync(f, bb, keep_corr=False); fast = eng.sync_fast(f, bb)
     k = (ref.npeaks & 0xFFFF).clamp(max=32); mask = torch.arange(32, device=dev)[None, :] < k[:, None]
