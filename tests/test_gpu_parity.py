@@ -747,3 +747,26 @@ def test_aead_seal_kernel(engine, oracle):
     assert bool(torch.all(ok == 1)) and np.array_equal(pt.cpu().numpy(), plain)
     wok, wpt = oracle.validate_blobs(key, blobs[:64], ctrs[:64])
     assert wok.all() and np.array_equal(wpt, plain[:64])
+
+
+def test_option_and_argument_errors(engine):
+    """Error behaviour of the newer entry points: unknown / out-of-range options, mismatched shapes and key lengths raise
+    (NativeError from the C ABI's negative return codes, ValueError from the host wrappers) and leave the engine usable."""
+    from echoseal_amd._native import NativeError
+    with pytest.raises(NativeError):
+        engine.set_option("no_such_option", 1)
+    with pytest.raises(NativeError):
+        engine.set_option("scl_multi", 7)
+    with pytest.raises(ValueError):
+        engine.schedule(b"\x00" * 16, b"\x00" * 31, ctr0=0, n=4)
+    with pytest.raises(ValueError):
+        engine.aead_seal(b"\x00" * 32, torch.zeros((3, 12), dtype=torch.uint8), torch.zeros((4, 27), dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        engine.aead_check(b"\x00" * 32, torch.zeros((3, 54), dtype=torch.uint8), torch.zeros(3, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        engine.make_frames(__import__("echoseal_amd.crypto", fromlist=["SecureChannel"]).SecureChannel(KEY), KEY,
+                           torch.arange(4), torch.zeros((3, 55), dtype=torch.uint8))
+    engine.set_option("scl_multi", -1)
+    pn, band = engine.schedule(b"\x01" * 16, KEY, ctr0=0, n=0)            # empty batches are fine
+    assert pn.shape == (0, 152) and band.numel() == 0
+    assert engine.resample(np.zeros(0, np.float32), 44100, 48000).numel() == 0
