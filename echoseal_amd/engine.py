@@ -300,6 +300,24 @@ class RxEngine:
                                                           _ptr(y_ws), _ptr(frames), self._stream()), "es_tx_frames_batch")
         return frames
 
+    def synthetic_frames(self, key32: bytes, ctr0: int, n: int, *, seed: int = 20260101):
+        """The benchmark workloads' frames for counters ctr0 .. ctr0+n-1, made wholly on the device (SURVEY 8d:
+        plaintext b"ESAL" | ctr_be32 | nonce8 | pad11 sealed with a 12-byte nonce, random bytes from a seeded torch
+        generator, then `make_frames`).  -> (frames float32 [n,1215], payloads uint8 [n,55]).  Input synthesis for
+        configs 3 and 4, where 65 536 .. 2^20 frames would take the host embedder minutes."""
+        from .crypto import SecureChannel
+        sec = SecureChannel(key32)
+        g = torch.Generator(device=self.device); g.manual_seed(int(seed) + int(ctr0))
+        rnd = torch.randint(0, 256, (n, 31), dtype=torch.uint8, device=self.device, generator=g)
+        ctr = torch.arange(ctr0, ctr0 + n, dtype=torch.int64, device=self.device)
+        plain = torch.empty((n, 27), dtype=torch.uint8, device=self.device)
+        plain[:, :4] = torch.tensor(list(b"ESAL"), dtype=torch.uint8, device=self.device)
+        for k in range(4):
+            plain[:, 4 + k] = ((ctr >> (8 * (3 - k))) & 0xFF).to(torch.uint8)
+        plain[:, 8:27] = rnd[:, :19]
+        payloads = self.aead_seal(sec._aead._key, rnd[:, 19:31].contiguous(), plain)
+        return self.make_frames(sec, key32, ctr, payloads), payloads
+
     # ------------------------------------------------------------------ after the list decoder (SURVEY 8 f-2)
     def _ctr_dev(self, ctrs) -> torch.Tensor:
         """Frame counters as the 32-bit words the kernels compare against (stored in an int32 tensor)."""
