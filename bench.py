@@ -73,6 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on fewer GPUs)")
     ap.add_argument("--scl-streams", type=int, default=2, help="list-decoder streams (= batches in flight) of the pipeline")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: = --scl-streams)")
+    ap.add_argument("--lanes", type=int, default=0, help="pipeline as K independent whole-chain lanes (0: front end + list-decoder streams)")
     ap.add_argument("--scl-multi", type=int, default=-1, help="es_set_option scl_multi: -1 auto, 0 one frame per wave, 1 several")
     return ap.parse_args(argv)
 
@@ -215,7 +216,7 @@ def run_rank(a) -> None:
     # A step = one batch through the whole hot path.  Batches are independent, so the engine's streaming pipeline
     # (echoseal_amd.engine.DecodePipeline) keeps two in flight: the front end of batch k+2 starts when batch k leaves,
     # beside the list decoder of batch k+1.  Every step's outputs are complete at the final sync.
-    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None)
+    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None, lanes=a.lanes)
     for e in pipe.scl_engs:
         e.set_option("scl_multi", a.scl_multi)
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "es_tx_frames_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_char_p, c_char_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "es_resample_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "es_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "es_softplus_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "es_aead_check_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "es_aead_seal_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "es_select_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

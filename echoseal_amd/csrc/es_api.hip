@@ -357,6 +357,16 @@ int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8
     return es_launch_polar_encode(ctx, info_dev, B, code_dev, (hipStream_t)stream);
 }
 
+int es_softplus_batch(es_ctx* ctx, const double* t_dev, int64_t n, double* out_dev, void* stream)
+{
+    if (!ctx) return ES_EINVAL;
+    if (n < 0) return fail(ctx, ES_EINVAL, "es_softplus_batch: negative count");
+    if (n == 0) return ES_OK;
+    if (!t_dev || !out_dev) return fail(ctx, ES_EINVAL, "es_softplus_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    return es_launch_softplus(ctx, t_dev, n, out_dev, (hipStream_t)stream);
+}
+
 int es_aead_check_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* blobs_dev, int64_t n, int group,
                         const uint32_t* ctr_dev, uint8_t* ok_dev, uint8_t* plain_dev, void* stream)
 {

@@ -64,6 +64,7 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
 int es_launch_scl(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
                   uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
                   uint8_t* cand_ok, int32_t* ncand, hipStream_t st);
+int es_launch_softplus(es_ctx* ctx, const double* t, int64_t n, double* out, hipStream_t st);
 int es_launch_polar_encode(es_ctx* ctx, const uint8_t* info, int64_t B, uint8_t* code, hipStream_t st);
 int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, const uint8_t* band,
                   double* y, float* y32, hipStream_t st);

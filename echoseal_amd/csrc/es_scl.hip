@@ -589,6 +589,16 @@ __global__ __launch_bounds__(256) void es_polar_encode_kernel(const uint8_t* inf
     }
 }
 
+// ---- diagnostic: the device's log1p(exp(t)) (es_softplus_neg) on a vector, for the bit-for-bit parity test ----------
+__global__ __launch_bounds__(256) void es_softplus_kernel(const double* t, long long n, const uint64_t* exp_tab, double* out)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t s_exp[ES_EXP_TAB_WORDS];
+    for (int i = threadIdx.x; i < ES_EXP_TAB_WORDS; i += blockDim.x) s_exp[i] = exp_tab[i];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = es_softplus_neg(t[i], s_exp);
+}
+
 template <int L>
 long long scl_blocks(const es_ctx* ctx, long long B)
 {
@@ -672,6 +682,15 @@ int es_launch_scl(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int
         case 32: return launch_scl<32>(ctx, a, B, st);
         default: ctx->err = "list_size must be one of 1,2,4,8,16,32"; return ES_EINVAL;
     }
+}
+
+int es_launch_softplus(es_ctx* ctx, const double* t, int64_t n, double* out, hipStream_t st)
+{
+    long long blocks = (n + 255) / 256;
+    if (blocks > (long long)ctx->num_cu * 16) blocks = (long long)ctx->num_cu * 16;
+    hipLaunchKernelGGL(es_softplus_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t, (long long)n, ctx->d_exp_tab, out);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
 }
 
 int es_launch_polar_encode(es_ctx* ctx, const uint8_t* info, int64_t B, uint8_t* code, hipStream_t st)

@@ -25,26 +25,34 @@ constexpr int MP = 4;                              // lanes per path
 constexpr int MNP = 16;                            // paths per wave
 constexpr int MLGP = 2;                            // log2(MP)
 constexpr int MRD = NLEV - MLGP;                   // depths MRD..10 (sizes 4, 2, 1) live in registers
-constexpr int MGDEPTH = 4;                         // depths 1..4 live in global scratch
-constexpr int MGSLOT = 512 + 256 + 128 + 64;       // doubles per path slot in global scratch
-constexpr int MROW = 68;                           // depths 5..7 at [S, 2S), S = 32, 16, 8; + 4 pad: a path's row starts 8 banks after its neighbour's (16 paths x 4 lanes read conflict-free)
+constexpr int MGDEPTH = 5;                         // depths 1..5 live in global scratch
+constexpr int MGSLOT = 512 + 256 + 128 + 64 + 32;  // doubles per path slot in global scratch
+constexpr int MROW = 36;                           // depths 6..7 at [S, 2S), S = 16, 8; + 4 pad: a path's row starts 8 banks after its neighbour's (16 paths x 4 lanes read conflict-free)
+constexpr int MWIN = KINFO / 32;                   // trace-back windows of 32 information bits
 constexpr int MWPB = 4;                            // waves per block
+#ifndef ES_MULTI_MINW
+#define ES_MULTI_MINW 3                            // waves per SIMD the register allocation must allow (LDS admits that many blocks per CU)
+#endif
+#ifndef ES_MULTI_ILP
+#define ES_MULTI_ILP 1                             // independent f evaluations in flight per lane in the slot-storage loops
+#endif
+constexpr int MMINW = ES_MULTI_MINW;
 
 template <int L>
 struct MWave {
-    static constexpr bool NIB = L <= 8;            // (parent_local << 1) | bit fits a nibble up to L = 8
     double   alphaS[MNP][MROW];
     double   candm[2 * MNP];                       // frame fr: [2*L*fr, 2*L*(fr+1))
     uint32_t betaL[MNP][32];                       // left-sibling partial sums, block of S bits at bit S
     uint32_t curb[MNP][16];
     uint32_t hardw[32];
-    uint8_t  tbn[KINFO][NIB ? MNP / 2 : MNP];      // trace-back: nibbles (paths 2k | 2k+1 << 4) or one byte per path
+    uint32_t tbw[MWIN][MNP];                       // trace-back by windows of 32 information bits: the window's bits (first = MSB) ...
+    uint8_t  tba[MWIN][MNP];                       // ... and the path (within the frame) this path descended from at the window's start
     uint8_t  sel[MNP];
     uint8_t  outb[MNP][56];
 };
 
 template <int L>
-__global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kernel(SclArgs a)
+__global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_kernel(SclArgs a)
 {
     constexpr int P = MP, LGP = MLGP, RD = MRD;
     constexpr int FR = MNP / L;                    // frames per wave
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
         for (int k = 0; k <= LGP; ++k) ar[k] = 0.0;
         double sp_diff = 0.0, sp_sum = 0.0, lp_odd = 0.0;
         uint32_t b0 = 0;
+        uint32_t hist = 0, anc = 0;       // trace-back window (see the sort)
         uint32_t frozen_word = 0;
         int cnt = 1;                      // live paths per frame
         int info_idx = 0;
@@ -191,13 +200,16 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
                     }
                 } else {
                     int j = j0;
+#if ES_MULTI_ILP == 2
                     for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
                         double a0, c0, a1, c1; load_pair(j, a0, c0); load_pair(j + jst, a1, c1);
                         const double o0 = es_polar_f(a0, c0, tab);
                         const double o1 = es_polar_f(a1, c1, tab);
                         store_out(j, o0); store_out(j + jst, o1);
                     }
-                    if (j < S) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
+#endif
+                    // one f (= two interleaved softplus chains) in flight per lane: the other waves of the SIMD hide the rest
+                    for (; j < S; j += jst) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
                 }
                 if (d <= MGDEPTH) wave_fence_global(); else wave_fence_lds();
                 ptrA = ptr_set(ptrA, d, own);
@@ -259,6 +271,7 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
                     for (int h = S >> 1; h >= P; h >>= 1) {           // nodes of 2h values -> children of h values
                         const int lh = 31 - __builtin_clz((unsigned)h);
                         int idx = q;
+#if ES_MULTI_ILP == 2
                         for (; idx + P < (S >> 1); idx += 2 * P) {    // two independent f chains in flight
                             const int e0 = ((idx >> lh) << (lh + 1)) + (idx & (h - 1));
                             const int e1 = (((idx + P) >> lh) << (lh + 1)) + ((idx + P) & (h - 1));
@@ -268,7 +281,8 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
                             st(e0, o0); st(e0 + h, es_polar_g(a0, c0, 0u));
                             st(e1, o1); st(e1 + h, es_polar_g(a1, c1, 0u));
                         }
-                        if (idx < (S >> 1)) {
+#endif
+                        for (; idx < (S >> 1); idx += P) {
                             const int e0 = ((idx >> lh) << (lh + 1)) + (idx & (h - 1));
                             const double a0 = ld(e0), c0 = ld(e0 + h);
                             st(e0, es_polar_f(a0, c0, tab)); st(e0 + h, es_polar_g(a0, c0, 0u));
@@ -384,13 +398,15 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
                 for (int k = 0; k <= LGP; ++k)
                     if (((i + 1) & ((1 << (LGP - k)) - 1)) != 0) ar[k] = __shfl(ar[k], parent * P + q);
                 if (!(i & 1)) lp_odd = __shfl((q & 1) ? sp_diff : sp_sum, src);
-                // trace-back nibble (parent within the frame, bit); paths 2k and 2k+1 share a byte
-                const uint32_t nib = ((uint32_t)(cc >> 1) << 1) | bit;
-                if constexpr (MWave<L>::NIB) {
-                    const uint32_t nib_hi = (uint32_t)__shfl((int)nib, lane + P);
-                    if (q == 0 && !(path & 1)) W.tbn[info_idx][path >> 1] = (uint8_t)(nib | (nib_hi << 4));
-                } else {
-                    if (q == 0) W.tbn[info_idx][path] = (uint8_t)nib;
+                // trace-back by windows of 32 information bits: a path carries the bits it decided inside the current
+                // window (hist) and the path it descended from at the window's start (anc); both follow the path at a
+                // sort, and a full window is written to LDS once: the final trace-back then takes 14 steps, not 448.
+                {
+                    const uint32_t anc_own = (info_idx & 31) == 0 ? (uint32_t)pl : anc;
+                    const uint32_t packed = __shfl((int)((info_idx & 31) == 0 ? 0u : hist), parent * P);
+                    anc = (uint32_t)__shfl((int)anc_own, parent * P);
+                    hist = (packed << 1) | bit;
+                    if ((info_idx & 31) == 31 && q == 0) { W.tbw[info_idx >> 5][path] = hist; W.tba[info_idx >> 5][path] = (uint8_t)anc; }
                 }
                 cnt = keep;
                 ++info_idx;
@@ -449,13 +465,11 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? 2 : 1)) void es_scl_multi_kern
         }
         if (q == 0 && pl < cnt) {
             int cur = pl;
-            uint32_t acc = 0;
-            for (int tt = KINFO - 1; tt >= 0; --tt) {
-                const int gp = fp0 + cur;
-                const uint32_t c = MWave<L>::NIB ? (uint32_t)((W.tbn[tt][gp >> 1] >> (4 * (gp & 1))) & 15u) : (uint32_t)W.tbn[tt][gp];
-                acc |= (c & 1u) << (7 - (tt & 7));
-                cur = (int)(c >> 1);
-                if ((tt & 7) == 0) { W.outb[path][tt >> 3] = (uint8_t)acc; acc = 0; }
+            for (int w = MWIN - 1; w >= 0; --w) {
+                const uint32_t word = W.tbw[w][fp0 + cur];                   // information bits 32w .. 32w+31, first = MSB
+                cur = (int)W.tba[w][fp0 + cur];
+                W.outb[path][4 * w + 0] = (uint8_t)(word >> 24); W.outb[path][4 * w + 1] = (uint8_t)(word >> 16);
+                W.outb[path][4 * w + 2] = (uint8_t)(word >> 8);  W.outb[path][4 * w + 3] = (uint8_t)word;
             }
             if (f_store) {
                 const int ok = crc8_bytes(W.outb[path], ES_INFO_BYTES) == W.outb[path][ES_INFO_BYTES];
@@ -479,7 +493,7 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     constexpr int FR = MNP / L;
     const long long groups = (B + FR - 1) / FR;
     long long blocks = (groups + MWPB - 1) / MWPB;
-    const long long max_blocks = (long long)ctx->num_cu * 2;    // LDS admits two blocks per CU
+    const long long max_blocks = (long long)ctx->num_cu * MMINW;    // LDS and registers admit MMINW blocks per CU
     if (blocks > max_blocks) blocks = max_blocks;
     if ((size_t)blocks * MWPB * MNP * MGSLOT * sizeof(double) > ctx->scl_scratch_bytes) {
         ctx->err = "es_scl_batch: scratch slab too small for the multi-frame kernel"; return ES_ENOMEM;
@@ -495,7 +509,7 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
 
 size_t es_scl_multi_scratch_bytes(const es_ctx* ctx)
 {
-    return (size_t)ctx->num_cu * 2 * MWPB * MNP * MGSLOT * sizeof(double);
+    return (size_t)ctx->num_cu * MMINW * MWPB * MNP * MGSLOT * sizeof(double);
 }
 
 int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,

@@ -53,6 +53,7 @@ class WatermarkDetector:
             raise RuntimeError(f"Header PN length {self._hdr_pn_sy.size} != expected {HDR_L}")
         self._engine = engine
         self._trace: list[tuple[int, int, int]] | None = None   # set to [] to record (band_lo, peak, ctr) tries
+        self._hdr_trace: list[tuple[float, float, float]] | None = None   # set to [] to record every header decode of a scan
 
     # ------------------------------------------------------------------ engine plumbing
     @property
@@ -136,6 +137,8 @@ class WatermarkDetector:
             frame = y[start:start + FRAME_LEN]
             ctr_est = int(round(start / FRAME_LEN))
             hdr_ok, ctr_lo16, _score = self._decode_header(frame, band)
+            if self._hdr_trace is not None:
+                self._hdr_trace.append((float(hdr_ok), float(ctr_lo16), float(_score)))
             cands: list[int] = []
             if hdr_ok:                                     # rtwm/detector.py:122-127
                 for ctr in range(max(0, ctr_est - WIDE_DELTA), ctr_est + WIDE_DELTA + 1):

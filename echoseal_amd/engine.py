@@ -227,6 +227,13 @@ class RxEngine:
             "es_scl_batch")
         return res
 
+    def softplus(self, t: torch.Tensor) -> torch.Tensor:
+        """Diagnostic: log1p(exp(t)) for t <= 0 as the list decoder evaluates it on the device (float64 in, float64 out)."""
+        t = t.contiguous()
+        out = torch.empty_like(t)
+        nat.check(self._ctx, self._lib.es_softplus_batch(self._ctx, _ptr(t), t.numel(), _ptr(out), self._stream()), "es_softplus_batch")
+        return out
+
     def polar_encode(self, info: torch.Tensor) -> torch.Tensor:
         info = info.contiguous()
         B = info.shape[0]
@@ -307,9 +314,14 @@ class RxEngine:
         configs 3 and 4, where 65 536 .. 2^20 frames would take the host embedder minutes."""
         from .crypto import SecureChannel
         sec = SecureChannel(key32)
-        g = torch.Generator(device=self.device); g.manual_seed(int(seed) + int(ctr0))
-        rnd = torch.randint(0, 256, (n, 31), dtype=torch.uint8, device=self.device, generator=g)
         ctr = torch.arange(ctr0, ctr0 + n, dtype=torch.int64, device=self.device)
+        # 31 random bytes per frame from a counter-based hash of (seed, ctr, byte index), so that a frame does not
+        # depend on how the counter range is cut into batches or shards (32-bit multiply-xorshift rounds in int64)
+        h = (ctr[:, None] * 31 + torch.arange(31, dtype=torch.int64, device=self.device)[None, :] + (int(seed) & 0xFFFFFF) * 1_000_003) & 0xFFFFFFFF
+        for _ in range(3):
+            h = (h * 0x45D9F3B) & 0xFFFFFFFF
+            h = h ^ (h >> 16)
+        rnd = (h & 0xFF).to(torch.uint8)
         plain = torch.empty((n, 27), dtype=torch.uint8, device=self.device)
         plain[:, :4] = torch.tensor(list(b"ESAL"), dtype=torch.uint8, device=self.device)
         for k in range(4):
@@ -423,10 +435,21 @@ class DecodePipeline:
     At most `depth` (= scl_streams) batches are in flight.  Results are complete after `wait(result)` / `synchronize()`;
     values are those of decode_batch (same kernels, same order per batch)."""
 
-    def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None):
+    def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None, lanes: int = 0):
         self.eng = eng
         self.list_size = int(list_size)
         dev = eng.device
+        # `lanes` > 0: the other arrangement -- K independent lanes, each one HIP stream (= one hardware queue) with its
+        # own context that runs the WHOLE chain of its batches (k, k+K, ...) in order; no cross-stream events at all.
+        self.lanes = max(0, int(lanes))
+        if self.lanes:
+            self.lane_streams = [torch.cuda.Stream(dev) for _ in range(self.lanes)]
+            self.lane_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in range(self.lanes - 1)]
+            self.scl_engs = self.lane_engs
+            self.backs = self.lane_streams
+            self.front = self.side = None
+            self._k = 0
+            return
         # the short front-end kernels get dispatch priority over the long-running list decoders
         self.front = torch.cuda.Stream(dev, priority=-1)
         self.side = torch.cuda.Stream(dev, priority=-1)
@@ -445,6 +468,26 @@ class DecodePipeline:
         eng = self.eng
         if frames.shape[1] - 62 > eng.FAST_MAX_LAGS:
             raise ValueError("DecodePipeline serves frame-sized records (use RxEngine.decode_batch for long captures)")
+        if self.lanes:
+            j = self._k % self.lanes
+            self._k += 1
+            st, e = self.lane_streams[j], self.lane_engs[j]
+            st.wait_stream(torch.cuda.current_stream(eng.device))
+            with torch.cuda.stream(st):
+                y, y32 = e.bpf2(frames, band)
+                if xcorr_events is not None:
+                    xcorr_events[0].record()
+                corr32 = e.xcorr32(y32, band)
+                if xcorr_events is not None:
+                    xcorr_events[1].record()
+                thr, peaks, npeaks, flags = e.pick_exact(corr32, y, band)
+                llr = e.llr(y, band, pn_rows, start=start, variant=0)
+                scl = e.scl(llr, list_size=self.list_size, skip_if_hard_ok=True)
+                done = torch.cuda.Event()
+                done.record()
+            for t in (frames, band, pn_rows):
+                t.record_stream(st)
+            return SyncResult(y, None, thr, peaks, npeaks, flags=flags), llr, scl, done
         self.front.wait_stream(torch.cuda.current_stream(eng.device))   # inputs were produced on the caller's stream
         if len(self._inflight) >= self.depth:                           # at most `depth` batches in flight
             self.front.wait_event(self._inflight.pop(0))
@@ -479,7 +522,8 @@ class DecodePipeline:
         result[3].synchronize()
 
     def synchronize(self) -> None:
-        self.front.synchronize(); self.side.synchronize()
+        if self.front is not None:
+            self.front.synchronize(); self.side.synchronize()
         for b in self.backs:
             b.synchronize()
 

@@ -180,6 +180,11 @@ int es_tx_frames_batch(es_ctx* ctx, const uint8_t* code_dev, const uint8_t* pn_r
 int es_resample_batch(es_ctx* ctx, const void* x_dev, int dtype, int64_t B, int64_t n_in, const void* h_tf_dev, int h_per_phase,
                       int up, int down, int64_t y0, int64_t n_out, void* out_dev, void* stream);
 
+/* Diagnostic: out[i] = log1p(exp(t[i])) for t[i] <= 0 exactly as the list decoder's f / penalty evaluate it on the device
+ * (np.logaddexp / np.log1p(np.exp(.)) of rtwm/fastpolar.py:18-23, 32-40 through the C library's exp and log1p) -- lets a
+ * test compare the device arithmetic with the host C library bit for bit.  t_dev, out_dev float64 [n].                   */
+int es_softplus_batch(es_ctx* ctx, const double* t_dev, int64_t n, double* out_dev, void* stream);
+
 /* Tuning knobs; results never depend on them.  "scl_multi": -1 (default) lets es_scl_batch choose between one
  * frame per wavefront and 16/L frames per wavefront (list sizes <= 8; better lane use at the bottom of the LLR
  * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.                                   */

@@ -1,0 +1,47 @@
+"""bench.py's own launcher: `python bench.py --gpus N` without WORLD_SIZE starts N rank processes itself and fails
+loudly when the devices are not there; on a GPU box a two-rank rehearsal (gloo, both ranks on the one GPU) must print
+n_gpus = 2 and the strong-scaling leg's checksum must not depend on the number of ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    return env
+
+
+def test_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(n + 2), "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "GPU(s) are visible" in p.stderr and not p.stdout.strip()
+
+
+def test_rank_refuses_world_size_mismatch():
+    env = dict(_env(), WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_and_checksum_independent_of_world_size():
+    common = ["--steps", "4", "--warmup", "1", "--legs", "c4", "--c4-frames", "16384", "--c4-chunk", "4096", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, BENCH, "--gpus", "1"] + common, env=_env(), capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo"] + common, env=_env(), capture_output=True,
+                         text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1]); j2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["config"]["world_size"] == 2
+    assert j2["legs"]["c4"]["frames_per_rank"] == 8192 and j2["legs"]["c4"]["scaling"] == "strong"
+    assert j1["legs"]["c4"]["checksum"] == j2["legs"]["c4"]["checksum"]
+    assert j1["legs"]["c4"]["frames_with_sync_offset_0"] == j2["legs"]["c4"]["frames_with_sync_offset_0"] == 16384

@@ -1,0 +1,155 @@
+"""HIP kernels (through the C ABI) against the round-2 REFERENCE fixtures (tests/golden/*, captured by running the
+reference: oracle/refshim/gen_golden_r2.py).  Bars: sync offsets / decoded bits exact, thr <= 1e-12, LLR <= 1e-5."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from echoseal_amd.crypto import SecureChannel
+from echoseal_amd.tables import pack_tables
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KEY = b"\xAA" * 32
+
+
+def _g(name):
+    return np.load(os.path.join(HERE, "golden", name))
+
+
+def _dev(eng, *arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(eng.device) for a in arrs]
+
+
+def test_c3_windows_sync_header_llr_vs_reference(engine):
+    g = _g("c3_windows.npz")
+    n = g["win"].shape[0]
+    win, band = _dev(engine, g["win"], g["band"])
+    sec = SecureChannel(KEY)
+    pn, = _dev(engine, sec.pn_bytes_batch([int(c) for c in g["ctr"]], 152))
+    hdr_pn, = _dev(engine, np.packbits(sec.pn_bits(0, 128)).reshape(1, 16))
+    for name in ("fast", "f64"):
+        sy = engine.sync_fast(win, band) if name == "fast" else engine.sync(win, band, keep_corr=True)
+        thr = sy.thr.cpu().numpy(); pk = sy.peaks.cpu().numpy(); npk = sy.npeaks.cpu().numpy()
+        assert np.max(np.abs(thr - g["thr"])) < 1e-12, name
+        for i in range(n):
+            k = min(int(g["npeaks"][i]), 32)
+            assert (int(npk[i]) & 0xFFFF) == k and bool(npk[i] >> 30) == bool(g["fallback"][i]), (name, i)
+            assert list(pk[i, :k]) == list(g["peaks"][i, :k]), (name, i)          # sync offsets: exact
+        if name == "f64":
+            corr = sy.corr.cpu().numpy()
+            for i in range(16):
+                assert np.max(np.abs(corr[i] - g[f"corr/{i:03d}"])) < 1e-12
+    y = sy.y
+    # header decode at the peaks the reference visited
+    rows, starts, want = [], [], []
+    for i in range(n):
+        vis = [int(p) for p in g["peaks"][i, :min(int(g["npeaks"][i]), 25)] if p + 1215 <= 2048][:5]
+        for j, st in enumerate(vis):
+            rows.append(i); starts.append(st); want.append(g["hdr"][i, j])
+    rows_t = torch.tensor(rows, device=engine.device)
+    ok, val, score = engine.header(y[rows_t].contiguous(), band[rows_t].contiguous(), hdr_pn,
+                                   start=torch.tensor(starts, dtype=torch.int32, device=engine.device))
+    want = np.array(want)
+    assert np.array_equal(ok.cpu().numpy().astype(bool), want[:, 0].astype(bool))
+    assert np.array_equal(val.cpu().numpy(), want[:, 1].astype(np.int64))
+    assert np.max(np.abs(score.cpu().numpy() - want[:, 2]) / np.maximum(1.0, np.abs(want[:, 2]))) <= 1e-4
+    # _llr at the reference's first peak (frame may be cut short by the window end)
+    start = torch.from_numpy(g["peaks"][:, 0].astype(np.int32)).to(engine.device)
+    worst = amb = 0
+    for variant, key in ((0, "llr0"), (1, "llr1")):
+        llr, best_s, score2 = engine.llr(y, band, pn, start=start, variant=variant, want_diag=True)
+        llr = llr.cpu().numpy(); best_s = best_s.cpu().numpy(); sc = score2.cpu().numpy()
+        for i in range(n):
+            if 2048 - int(g["peaks"][i, 0]) <= 191:
+                assert not llr[i].any() and not g[key][i].any()
+                continue
+            if best_s[i] != g["best_s"][i, variant]:
+                assert (sc[i, 0] - sc[i, 1]) / max(abs(sc[i, 0]), 1e-30) < 1e-5, (i, variant)     # tie-ambiguous
+                amb += 1
+                continue
+            worst = max(worst, float(np.max(np.abs(llr[i] - g[key][i]))))
+    assert worst <= 1e-5 and amb <= 4, (worst, amb)
+
+
+def test_multi_peak_records_vs_reference(engine):
+    g = _g("sync_multi.npz")
+    for i in range(int(g["count"])):
+        t = f"{i:02d}"
+        x, band = _dev(engine, g[f"{t}/x"].reshape(1, -1), np.array([int(g[f"{t}/band"])], np.uint8))
+        ref = list(g[f"{t}/peaks"])
+        for name in ("fast", "f64"):
+            sy = engine.sync_fast(x, band) if (name == "fast" and x.shape[1] - 62 <= engine.FAST_MAX_LAGS) else engine.sync(x, band)
+            assert abs(float(sy.thr[0]) - float(g[f"{t}/thr"])) < 1e-12
+            k = int(sy.npeaks[0]) & 0xFFFF
+            assert k == min(len(ref), 32) and bool(int(sy.npeaks[0]) >> 30) == bool(g[f"{t}/fallback"])
+            assert list(sy.peaks[0, :k].cpu().numpy()) == ref[:k], (t, name)
+
+
+@pytest.mark.parametrize("multi", [0, 1])
+def test_polar_bulk_vs_reference(engine, multi):
+    """1 024 LLR vectors: final SCL-8 lists bit-identical (bits, metrics, CRC flags) to the reference run on the C
+    library's exp/log1p; hard-decision shortcut and (info, ok) through es_select_batch."""
+    g = _g("polar_bulk_glibc.npz")
+    llr, = _dev(engine, g["llr"])
+    engine.set_option("scl_multi", multi)
+    try:
+        res = engine.scl(llr, list_size=8, skip_if_hard_ok=False)
+        short = engine.scl(llr, list_size=8, skip_if_hard_ok=True)
+    finally:
+        engine.set_option("scl_multi", -1)
+    took = g["took_list"]
+    assert np.array_equal(short.ncand.cpu().numpy() > 0, took)                   # the shortcut fires exactly where the reference's did
+    assert np.array_equal(res.cand_info.cpu().numpy()[took], g["cand_info"][took])
+    assert np.array_equal(res.cand_metric.cpu().numpy()[took].view(np.uint64), g["cand_metric"][took].view(np.uint64))
+    assert np.array_equal(res.cand_ok.cpu().numpy()[took], g["cand_crc"][took])
+    payload, ok, which = engine.select(short)
+    assert np.array_equal(payload.cpu().numpy(), g["info"])
+    assert np.array_equal(ok.cpu().numpy() == 1, g["ok"])
+
+
+def test_decode_with_validator_vs_reference(engine):
+    from echoseal_amd.engine import select_payload
+    from test_golden_r2 import _validator
+    g = _g("polar_validator.npz")
+    n = int(g["count"])
+    key = SecureChannel(KEY)._aead._key
+    by_L = {}
+    for i in range(n):
+        by_L.setdefault(int(g[f"{i:03d}/L"]), []).append(i)
+    for L, idx in by_L.items():
+        llr, = _dev(engine, np.stack([g[f"{i:03d}/llr"] for i in idx]))
+        res = engine.scl(llr, list_size=L, skip_if_hard_ok=False)
+        for r, i in enumerate(idx):
+            t = f"{i:03d}"
+            spec = str(g[f"{t}/spec"]); arg = g[f"{t}/arg"]
+            seen = []
+            payload, ok = select_payload(res, r, _validator(spec, arg, KEY, seen))
+            assert ok == bool(g[f"{t}/ok"]) and payload == g[f"{t}/info"].tobytes(), (i, spec)
+            assert seen == [s.tobytes() for s in g[f"{t}/seen"]], (i, spec)
+        # the detector's own validator on the GPU (es_select_batch with the AEAD key)
+        aead = [(r, i) for r, i in enumerate(idx) if str(g[f"{i:03d}/spec"]) == "aead"]
+        if aead:
+            want_ctr = np.zeros(len(idx), np.int64)
+            for r, i in aead:
+                want_ctr[r] = int(g[f"{i:03d}/arg"])
+            payload, ok, which = engine.select(res, key32=key, ctrs=torch.from_numpy(want_ctr))
+            payload = payload.cpu().numpy(); ok = ok.cpu().numpy()
+            for r, i in aead:
+                assert (ok[r] == 1) == bool(g[f"{i:03d}/ok"]) and payload[r].tobytes() == g[f"{i:03d}/info"].tobytes(), i
+
+
+def test_verify_3s_clip_follows_reference(engine):
+    from echoseal_amd.detector import WatermarkDetector
+    g = _g("verify3s.npz")
+    det = WatermarkDetector(KEY, list_size=1, engine=engine)
+    det._trace = []
+    det._hdr_trace = []
+    assert det.verify(g["clip"], 48_000) == bool(g["result"])
+    assert np.array_equal(np.array(det._trace, dtype=np.int64).reshape(-1, 3), g["trace"])
+    hdr = np.array(det._hdr_trace, dtype=np.float64).reshape(-1, 3)
+    assert hdr.shape == g["hdr"].shape
+    assert np.array_equal(hdr[:, :2], g["hdr"][:, :2])
+    assert np.max(np.abs(hdr[:, 2] - g["hdr"][:, 2]) / np.maximum(1.0, np.abs(g["hdr"][:, 2]))) <= 1e-4

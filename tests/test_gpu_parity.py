@@ -770,3 +770,27 @@ def test_option_and_argument_errors(engine):
     pn, band = engine.schedule(b"\x01" * 16, KEY, ctr0=0, n=0)            # empty batches are fine
     assert pn.shape == (0, 152) and band.numel() == 0
     assert engine.resample(np.zeros(0, np.float32), 44100, 48000).numel() == 0
+
+
+def test_device_softplus_bits(engine, oracle):
+    """The device's log1p(exp(t)) -- straight-line form with the guard-free division (es_div_normal) and the generic
+    fall-back -- against the HOST C library, bit for bit, on 3 million arguments over every range the decoder produces
+    (es_math.h is also what the oracle compiles, but with `/`; this is the check of the device-only division)."""
+    import ctypes
+    m = ctypes.CDLL("libm.so.6")
+    rng = np.random.default_rng(2026)
+    t = np.concatenate([
+        -np.abs(rng.normal(0, 6, 1_000_000)), -rng.uniform(0, 1.0, 500_000), -rng.uniform(0.85, 0.92, 200_000),
+        -rng.uniform(15, 45, 300_000), -rng.uniform(0, 800, 300_000), -np.abs(rng.normal(0, 3000, 200_000)),
+        -np.ldexp(rng.uniform(0.5, 1, 300_000), -rng.integers(0, 80, 300_000)),
+        -np.arange(0, 24.0, 1.0 / 8192),                                            # a regular grid (clipped-LLR differences)
+        np.array([0.0, -0.0, -0.8813735870195429, -0.881373587019543, -0.8813735870195432, -20.1, -20.101268236238414,
+                  -37.42994775023705, -37.5, -511.9, -512.0, -745.2, -1e-300, -2.0 ** -54, -2.0 ** -55, -np.inf])])
+    got = engine.softplus(torch.from_numpy(t).to(engine.device)).cpu().numpy()
+    want = oracle.log1p_vec(oracle.exp_vec(t))                                      # == libm (tests/test_oracle_math.py)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    exp_, log1p_ = m.exp, m.log1p
+    exp_.restype = log1p_.restype = ctypes.c_double; exp_.argtypes = log1p_.argtypes = [ctypes.c_double]
+    idx = rng.integers(0, t.size, 20000)
+    ref = np.array([log1p_(exp_(float(v))) for v in t[idx]])
+    assert np.array_equal(got[idx].view(np.uint64), ref.view(np.uint64))
