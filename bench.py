@@ -46,6 +46,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The streaming pipeline keeps 7 batches in flight on 7 HIP streams; the HIP runtime multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 KEY = b"\xAA" * 32
 XCORR_BYTES_PER_FRAME = 4 * 1215 + 4 * (1215 - 62)        # 9 472 B
@@ -73,8 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on fewer GPUs)")
     ap.add_argument("--scl-streams", type=int, default=2, help="list-decoder streams (= batches in flight) of the pipeline")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: = --scl-streams)")
-    ap.add_argument("--lanes", type=int, default=0, help="pipeline as K independent whole-chain lanes (0: front end + list-decoder streams)")
-    ap.add_argument("--scl-multi", type=int, default=-1, help="es_set_option scl_multi: -1 auto, 0 one frame per wave, 1 several")
+    ap.add_argument("--lanes", type=int, default=7, help="pipeline as K independent whole-chain lanes (0: front end + list-decoder streams)")
+    ap.add_argument("--scl-multi", type=int, default=1, help="es_set_option scl_multi for the pipelined headline: -1 auto, 0 one frame per wave, 1 several")
     return ap.parse_args(argv)
 
 
@@ -382,7 +385,9 @@ def run_rank(a) -> None:
                        "frames_per_gpu": B, "list_size": L, "frame_len": 1215, "fs": 48000,
                        "world_size": world, "backend": ("nccl (RCCL)" if a.backend == "nccl" else a.backend) if world > 1 else "none (single rank)",
                        "sharding": f"{world} x {B} frames, schedule broadcast from rank 0",
-                       "pipelining": "two batches in flight (DecodePipeline): the list decoders of consecutive steps overlap on two streams",
+                       "pipelining": (f"{a.lanes} batches in flight (DecodePipeline, whole-chain lanes: batch k runs band-pass .. list decoder on HIP stream k mod {a.lanes}, "
+                                      f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')})") if a.lanes else
+                                     f"{a.scl_streams} batches in flight (DecodePipeline: front-end stream + {a.scl_streams} list-decoder streams)",
                        "single_batch_latency_ms": single_ms,
                        "sync_offsets_ok": ok_sync, "frames_through_list_decoder": listed},
             "legs": out_legs,

@@ -254,7 +254,9 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double u = 1.0 + y;
     const int32_t hu0 = es_hi32(u);
     const int32_t kk = (hu0 >> 20) - 1023;
-    const double cn1 = (kk > 0) ? 1.0 - (u - y) : y - (u - 1.0);
+    /* y <= 1 here, so u <= 2 and es_log1p's two forms of the rounding error of 1 + y coincide: for u < 2 (kk == 0) it
+       takes y - (u - 1); at u == 2 (y == 1, kk == 1) its 1 - (u - y) and this expression are both exactly 0 */
+    const double cn1 = y - (u - 1.0);
     const int32_t hum = hu0 & 0x000fffff;
     const int big = hum >= 0x6a09e;
     const int32_t k1 = kk + (big ? 1 : 0);
@@ -264,7 +266,10 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double f = k0 ? y : un - 1.0;
     const int32_t k = k0 ? 0 : k1;
     const int32_t hu = k0 ? 1 : hu1;
-    const double c = es_div_normal(cn1, u);               /* only read when k != 0, where es_log1p divides exactly these */
+    /* es_log1p's k == 0 result f - (hfsq - s*(hfsq+R)) is its k != 0 expression with dk = 0 and c = 0 (0*ln2 terms and
+       "+ 0" are exact, and -(A - f) == f - A): one expression serves both once c is masked */
+    const double cq = es_div_normal(cn1, u);
+    const double c = (k == 0) ? 0.0 : cq;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     const double s = es_div_normal(f, 2.0 + f);
@@ -278,9 +283,7 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double R4 = ES_LP6 + z * ES_LP7;
     const double R = ((R1 + z2 * R2) + z4 * R3) + z6 * R4;
     const double sR = s * (hfsq + R);
-    const double res0 = f - (hfsq - sR);
-    const double resk = dk * ES_LN2_HI - ((hfsq - (sR + (dk * ES_LN2_LO + c))) - f);
-    double res = (k == 0) ? res0 : resk;
+    double res = dk * ES_LN2_HI - ((hfsq - (sR + (dk * ES_LN2_LO + c))) - f);
     const double rt = y - y * y * 0.5;
     res = tiny29 ? rt : res;
     /* Range of the straight-line form.  exp: every |t| < 512 -- below 2^-54 (in practice t == 0, which two LLRs clipped

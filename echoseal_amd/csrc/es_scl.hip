@@ -128,8 +128,10 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
             if (lane < ES_INFO_BYTES) a.hard_info[f * ES_INFO_BYTES + lane] = W.outb[0][lane];
             if (lane == 0) a.hard_ok[f] = (uint8_t)ok;
             wave_fence_lds();
-            if (ok && a.skip_if_hard_ok) {
+            if (ok && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
                 if (lane == 0) a.ncand[f] = 0;
+                for (int k = lane; k < L * ES_INFO_BYTES; k += 64) a.cand_info[f * L * ES_INFO_BYTES + k] = 0;
+                if (lane < L) { a.cand_metric[f * L + lane] = 0.0; a.cand_ok[f * L + lane] = 0; }
                 continue;
             }
         }

@@ -128,8 +128,11 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
             if (lane < ES_INFO_BYTES) a.hard_info[ff * ES_INFO_BYTES + lane] = W.outb[0][lane];
             if (lane == 0) a.hard_ok[ff] = (uint8_t)ok;
             wave_fence_lds();
-            if (ok && a.skip_if_hard_ok) { if (lane == 0) a.ncand[ff] = 0; }
-            else active_mask |= 1u << fi;
+            if (ok && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
+                if (lane == 0) a.ncand[ff] = 0;
+                for (int k = lane; k < L * ES_INFO_BYTES; k += 64) a.cand_info[ff * L * ES_INFO_BYTES + k] = 0;
+                if (lane < L) { a.cand_metric[ff * L + lane] = 0.0; a.cand_ok[ff * L + lane] = 0; }
+            } else active_mask |= 1u << fi;
         }
         if (active_mask == 0) continue;
         const bool f_store = f_valid && ((active_mask >> fr) & 1u);

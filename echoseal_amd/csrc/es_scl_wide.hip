@@ -116,8 +116,10 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
         }
         if (p < ES_INFO_BYTES) a.hard_info[f * ES_INFO_BYTES + p] = W.hbytes[p];
         __syncthreads();
-        if (W.flag && a.skip_if_hard_ok) {
+        if (W.flag && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
             if (p == 0) a.ncand[f] = 0;
+            for (int k = p; k < L * ES_INFO_BYTES; k += L) a.cand_info[f * L * ES_INFO_BYTES + k] = 0;
+            a.cand_metric[f * L + p] = 0.0; a.cand_ok[f * L + p] = 0;
             __syncthreads();
             continue;
         }

@@ -460,9 +460,11 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
                 __syncthreads();
             }
             if (threadIdx.x == 0) npeaks[rec] = kmax | (1 << 30);
+            total = kmax;
         } else if (threadIdx.x == 0) {
             npeaks[rec] = total;
         }
+        if ((int)threadIdx.x >= total && threadIdx.x < ES_MAX_PEAKS) peaks[rec * ES_MAX_PEAKS + threadIdx.x] = -1;   // unused tail
         if (threadIdx.x == 0) thr_out[rec] = thr;
         (void)s_flag;
         __syncthreads();

@@ -469,10 +469,12 @@ __global__ __launch_bounds__(64 * PW_WAVES) void es_pick_exact_wave_kernel(const
                 if (before < kmax) peaks[rec * ES_MAX_PEAKS + before] = ii;
             }
             if (lane == 0) npeaks[rec] = kmax | (1 << 30);
+            total = kmax;
             wave_fence_lds();
         } else if (lane == 0) {
             npeaks[rec] = total;
         }
+        if (lane >= total && lane < ES_MAX_PEAKS) peaks[rec * ES_MAX_PEAKS + lane] = -1;        // unused tail of the row
         if (lane == 0) { thr_out[rec] = thr; flags[rec] = 0; }
     }
 }
