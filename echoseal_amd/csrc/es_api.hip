@@ -39,7 +39,8 @@ es_ctx* es_create(int device, int list_size_max)
     hipDeviceProp_t prop;
     if (!g.ok || hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; delete ctx; return nullptr; }
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&ctx->d_tables, sizeof(es_band_tables)) != hipSuccess ||
+    if (hipMalloc(&ctx->d_nflag, sizeof(int)) != hipSuccess ||
+        hipMalloc(&ctx->d_tables, sizeof(es_band_tables)) != hipSuccess ||
         hipMalloc(&ctx->d_data_pos, sizeof(uint16_t) * ES_POLAR_N) != hipSuccess ||
         hipMalloc(&ctx->d_exp_tab, sizeof(kExpTab)) != hipSuccess ||
         hipMemcpy(ctx->d_exp_tab, kExpTab, sizeof(kExpTab), hipMemcpyHostToDevice) != hipSuccess) {
@@ -79,6 +80,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_wide_scratch) (void)hipFree(ctx->d_wide_scratch);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
     if (ctx->d_hdr_pn) (void)hipFree(ctx->d_hdr_pn);
+    if (ctx->d_nflag) (void)hipFree(ctx->d_nflag);
     delete ctx;
 }
 
@@ -172,18 +174,56 @@ int es_pick_exact_batch(es_ctx* ctx, const float* corr32_dev, const double* y_de
     /* float64 workspace for the (rare) records the float32 screen cannot settle; grows monotonically,
        so after a warm-up call nothing is allocated on the launch path */
     const size_t need = (size_t)B * n_lags * sizeof(double);
-    if (need > ctx->ws_corr_bytes) {
-        if (ctx->d_ws_corr) ES_HIP_CHECK(ctx, hipFree(ctx->d_ws_corr));
-        ctx->d_ws_corr = nullptr; ctx->ws_corr_bytes = 0;
-        ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_ws_corr, need));
-        ctx->ws_corr_bytes = need;
-    }
+    if (need > ctx->ws_corr_bytes) { const int rc0 = es_reserve(ctx, B, T); if (rc0) return rc0; }
     hipStream_t st = (hipStream_t)stream;
     int rc = es_launch_pick_exact(ctx, corr32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, st);
     if (rc) return rc;
-    rc = es_launch_xcorr_flagged(ctx, y_dev, B, T, band_dev, ctx->d_ws_corr, flags_dev, st);
+    rc = es_launch_xcorr_flagged(ctx, y_dev, B, T, band_dev, ctx->d_ws_corr, flags_dev, nullptr, st);
     if (rc) return rc;
-    return es_launch_pick_flagged(ctx, ctx->d_ws_corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, flags_dev, st);
+    return es_launch_pick_flagged(ctx, ctx->d_ws_corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, flags_dev, nullptr, st);
+}
+
+int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, int64_t B, int T,
+                        const uint8_t* band_dev, double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev,
+                        uint8_t* flags_dev, void* stream)
+{
+    ES_REQUIRE_READY(ctx);
+    if (B < 0) return fail(ctx, ES_EINVAL, "es_sync_fused_batch: negative size");
+    if (T < ES_PRE_L) return fail(ctx, ES_EINVAL, "es_sync_fused_batch: record shorter than the 63-chip template");
+    if (B == 0) return ES_OK;
+    if (!y32_dev || !y_dev || !band_dev || !thr_dev || !peaks_dev || !npeaks_dev || !flags_dev)
+        return fail(ctx, ES_EINVAL, "es_sync_fused_batch: null pointer");
+    DeviceGuard g(ctx->device);
+    const int n_lags = T - (ES_PRE_L - 1);
+    const size_t need = (size_t)B * n_lags * sizeof(double);       // float64 workspace of the redo pass (es_reserve sizes it ahead of time)
+    if (need > ctx->ws_corr_bytes) {
+        int rc0 = es_reserve(ctx, B, T);
+        if (rc0) return rc0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ES_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_nflag, 0, sizeof(int), st));
+    int rc = es_launch_sync_fused(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, ctx->d_nflag, st);
+    if (rc) return rc;
+    /* records the screen could not settle (flags != 0; counted on the device): redone by the float64 kernels -- two
+       launches of a few blocks that leave at once when the counter reads zero */
+    rc = es_launch_xcorr_flagged(ctx, y_dev, B, T, band_dev, ctx->d_ws_corr, flags_dev, ctx->d_nflag, st);
+    if (rc) return rc;
+    return es_launch_pick_flagged(ctx, ctx->d_ws_corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, flags_dev, ctx->d_nflag, st);
+}
+
+int es_reserve(es_ctx* ctx, int64_t B_max, int T_max)
+{
+    if (!ctx) return ES_EINVAL;
+    if (B_max < 0 || T_max < 0) return fail(ctx, ES_EINVAL, "es_reserve: negative size");
+    DeviceGuard g(ctx->device);
+    const size_t need = (T_max >= ES_PRE_L) ? (size_t)B_max * (size_t)(T_max - (ES_PRE_L - 1)) * sizeof(double) : 0;
+    if (need > ctx->ws_corr_bytes) {
+        if (ctx->d_ws_corr) ES_HIP_CHECK(ctx, hipFree(ctx->d_ws_corr));
+        ctx->d_ws_corr = nullptr; ctx->ws_corr_bytes = 0;
+        if (hipMalloc(&ctx->d_ws_corr, need) != hipSuccess) return fail(ctx, ES_ENOMEM, "es_reserve: device allocation of the float64 correlation workspace failed");
+        ctx->ws_corr_bytes = need;
+    }
+    return ES_OK;
 }
 
 int es_xcorr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const uint8_t* band_dev,
@@ -221,12 +261,7 @@ int es_sync_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int
     double* corr = corr_dev;
     if (!corr) {                                          // workspace grows monotonically; never freed in-call
         const size_t need = (size_t)B * n_lags * sizeof(double);
-        if (need > ctx->ws_corr_bytes) {
-            if (ctx->d_ws_corr) ES_HIP_CHECK(ctx, hipFree(ctx->d_ws_corr));
-            ctx->d_ws_corr = nullptr; ctx->ws_corr_bytes = 0;
-            ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_ws_corr, need));
-            ctx->ws_corr_bytes = need;
-        }
+        if (need > ctx->ws_corr_bytes) { const int rc0 = es_reserve(ctx, B, T); if (rc0) return rc0; }
         corr = ctx->d_ws_corr;
     }
     int rc = es_bpf_batch(ctx, frames_dev, dtype, B, T, band_dev, y_dev, stream);

@@ -38,6 +38,9 @@ struct es_ctx {
     void*   d_wide_scratch = nullptr; size_t wide_scratch_bytes = 0; int wide_slots = 0;   /* list sizes 64..256 */
     uint8_t* d_sbox = nullptr;        /* AES S-box (es_schedule_batch) */
     uint8_t* d_hdr_pn = nullptr;      /* packed header PN (es_tx_frames_batch) */
+    int*     d_nflag = nullptr;       /* records the fused sync kernel handed to the float64 kernels (per call) */
+    bool pick_attr_set = false;       /* per-device kernel attributes already raised for this context's device */
+    bool wide_attr_set = false;
     /* tuning (es_set_option) */
     int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
 };
@@ -71,10 +74,13 @@ int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, 
 int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uint8_t* band, float* corr32, hipStream_t st);
 int es_launch_pick_exact(es_ctx* ctx, const float* corr32, const double* y, int64_t B, int T, const uint8_t* band,
                          double* thr, int32_t* peaks, int32_t* npeaks, uint8_t* flags, hipStream_t st);
+int es_launch_sync_fused(es_ctx* ctx, const float* y32, const double* y, int64_t B, int T, const uint8_t* band, double* thr,
+                         int32_t* peaks, int32_t* npeaks, uint8_t* flags, int* nflag, hipStream_t st);
+/* redo of flagged records by the float64 kernels; nflag (nullable): device counter -- when it reads 0 every block leaves at once */
 int es_launch_xcorr_flagged(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
-                            const uint8_t* flags, hipStream_t st);
+                            const uint8_t* flags, const int* nflag, hipStream_t st);
 int es_launch_pick_flagged(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
-                           int32_t* npeaks, const uint8_t* flags, hipStream_t st);
+                           int32_t* npeaks, const uint8_t* flags, const int* nflag, hipStream_t st);
 int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
                     hipStream_t st);
 int es_launch_pick(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,

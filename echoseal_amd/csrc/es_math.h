@@ -266,10 +266,7 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double f = k0 ? y : un - 1.0;
     const int32_t k = k0 ? 0 : k1;
     const int32_t hu = k0 ? 1 : hu1;
-    /* es_log1p's k == 0 result f - (hfsq - s*(hfsq+R)) is its k != 0 expression with dk = 0 and c = 0 (0*ln2 terms and
-       "+ 0" are exact, and -(A - f) == f - A): one expression serves both once c is masked */
-    const double cq = es_div_normal(cn1, u);
-    const double c = (k == 0) ? 0.0 : cq;
+    const double c = es_div_normal(cn1, u);               /* only read when k != 0, where es_log1p divides exactly these */
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     const double s = es_div_normal(f, 2.0 + f);
@@ -283,7 +280,9 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double R4 = ES_LP6 + z * ES_LP7;
     const double R = ((R1 + z2 * R2) + z4 * R3) + z6 * R4;
     const double sR = s * (hfsq + R);
-    double res = dk * ES_LN2_HI - ((hfsq - (sR + (dk * ES_LN2_LO + c))) - f);
+    const double res0 = f - (hfsq - sR);
+    const double resk = dk * ES_LN2_HI - ((hfsq - (sR + (dk * ES_LN2_LO + c))) - f);
+    double res = (k == 0) ? res0 : resk;
     const double rt = y - y * y * 0.5;
     res = tiny29 ? rt : res;
     /* Range of the straight-line form.  exp: every |t| < 512 -- below 2^-54 (in practice t == 0, which two LLRs clipped

@@ -45,6 +45,22 @@ constexpr int XC_R_WINDOW = 17;                     // two waves per window: 2 x
 constexpr int XC_R_SMALL = 5;                       // lags per lane of the small-batch screen kernel
 constexpr double DELTA = 3e-5;
 
+// ------------------------------------------------------------------------------------ fused sync (declarations)
+// es_sync_fused_batch runs the correlation kernel below with FUSED = true: a wave owns whole records, the screen row
+// stays in LDS, and sync_pick_row() (defined after the picker's helpers) settles threshold and peaks from it -- HBM
+// sees 4 bytes per sample in and <= 150 bytes per record out ("4 860 + <= 64 B" per frame).
+constexpr int XF_WAVES = 2;                         // waves per block of the fused kernel (a block = 2 records in flight)
+constexpr int XF_MIN_WAVES = 2;                     // LDS (16-19 KB per wave) admits two waves per SIMD anyway
+struct FusedArgs {
+    const double* y64;                              // [B][T] float64 band-passed records (exact re-evaluations)
+    double* thr; int32_t* peaks; int32_t* npeaks; uint8_t* flags;
+    int* nflag;                                     // device counter of flagged records (nullable)
+};
+struct PwFixed;
+__device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, const double* tpl, long long rec, int lane,
+                              const FusedArgs& fo);
+__host__ __device__ __forceinline__ size_t xf_lds_per_wave(int ns2, int n_lags);
+
 // ------------------------------------------------------------------------------------ xcorr32
 // R = lags per lane.  R = 19 (one wave per frame-sized record) moves the fewest LDS bytes per FMA and is the
 // large-batch kernel; R = 5 spreads a record over four waves so that a 1 024-record launch still puts four
@@ -52,23 +68,31 @@ constexpr double DELTA = 3e-5;
 // (energy summation order); both satisfy the DELTA bound, and es_pick_exact_wave_kernel is exact for either.
 // TC = record length known at compile time (0: use the argument).  With TC = 1 215 (a frame) every bounds
 // test of the load / store loops folds away.
-template <int R, int TC>
-__global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel(const float* __restrict__ y, long long B,
+// FUSED = true (es_sync_fused_batch): an item is still a (record, segment) pair, but a wave walks ALL segments of its record,
+// writes the screen values into the record's LDS row instead of HBM, and after the last segment calls sync_pick_row().
+template <int R, int TC, bool FUSED>
+__global__ __launch_bounds__(64 * (FUSED ? XF_WAVES : XC_WAVES), FUSED ? XF_MIN_WAVES : XC_MIN_WAVES)
+void es_xcorr32_kernel(const float* __restrict__ y, long long B,
         int T_arg, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
-        float* __restrict__ corr)
+        float* __restrict__ corr, FusedArgs fo)
 {
     const int T = TC ? TC : T_arg;
     __builtin_amdgcn_s_setprio(3);      // a short kernel: when it shares a SIMD with a long-running list-decoder wave it should not queue behind it
     constexpr int SEG = 64 * R;
     constexpr int NS = SEG + ES_PRE_L - 1;
-    __shared__ float s_buf[XC_WAVES][NS + 2];
+    constexpr int WAVES = FUSED ? XF_WAVES : XC_WAVES;
+    __shared__ float s_buf[FUSED ? 1 : XC_WAVES][FUSED ? 4 : NS + 2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xf_smem[];      // FUSED: per wave [samples | screen row | PwFixed]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: item, record, band are scalar
-    float* s = s_buf[wv];
     const int n_lags = T - (ES_PRE_L - 1);
+    float* s = FUSED ? reinterpret_cast<float*>(xf_smem + wv * xf_lds_per_wave(NS + 2, n_lags)) : s_buf[wv];
+    float* const crow = s + (((NS + 2) + 3) & ~3);                            // FUSED: the record's screen row
     const int nseg = (n_lags + SEG - 1) / SEG;
     const long long n_items = B * nseg;
-    const long long stride = (long long)gridDim.x * XC_WAVES;
+    // non-fused: consecutive items go to consecutive waves.  Fused: a wave takes the nseg items of one record, then
+    // jumps to the record gridDim.x * WAVES further on.
+    const long long stride = FUSED ? (long long)gridDim.x * WAVES * nseg - (nseg - 1) : (long long)gridDim.x * WAVES;
     // item -> (record, segment) with 32-bit arithmetic (the launcher keeps n_items < 2^31); nseg is 1
     // for frame-sized records, so the division disappears on the hot path
     auto rec_of = [&](unsigned it) { return nseg == 1 ? it : it / (unsigned)nseg; };
@@ -86,8 +110,13 @@ __global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel
     };
     static_assert(R % 2 == 1, "R - 1 must be even (packed core energy)");
     if (lane < 2) s[NS + lane] = 0.0f;               // the zero-tap partner of the last lag reads one past the samples
-    unsigned item = (unsigned)(blockIdx.x * XC_WAVES + wv);
+    unsigned item = FUSED ? (unsigned)(blockIdx.x * WAVES + wv) * (unsigned)nseg : (unsigned)(blockIdx.x * WAVES + wv);
     if (item >= (unsigned)n_items) return;
+    // the item after `it`: fused waves finish their record first
+    auto next_item = [&](unsigned it) -> unsigned {
+        if (!FUSED) return it + (unsigned)stride;
+        return ((it + 1u) % (unsigned)nseg != 0u) ? it + 1u : it + (unsigned)stride;
+    };
     prefetch(item);
     // The body is instantiated twice, once peeled in front of the loop: inside the loop the 19 stores of
     // the previous record are then ALWAYS younger than the loads being waited for, so the compiler waits
@@ -98,7 +127,7 @@ __global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel
         const int bi = __builtin_amdgcn_readfirstlane(bi_next);
         #pragma unroll
         for (int u = 0; u < NST; ++u) { const int i = lane + 64 * u; if (i < NS) s[i] = stage[u]; }
-        if (item + (unsigned)stride < (unsigned)n_items) prefetch(item + (unsigned)stride);
+        if (next_item(item) < (unsigned)n_items) prefetch(next_item(item));
         const float* tpg = tabs->tpl32[bi];
         f32x2 tp2[32];                                       // tap pairs (2i, 2i+1), tap 63 = 0: SGPR pairs for the record
         #pragma unroll
@@ -158,27 +187,39 @@ __global__ __launch_bounds__(64 * XC_WAVES, XC_MIN_WAVES) void es_xcorr32_kernel
         // instead of sqrt + rcp.  Near-silent windows, and energies outside float32 range (|y| beyond
         // ~1e18, which would make the quotient silently wrong), take the careful form for the whole wave;
         // an overflowed energy becomes NaN, which sends the record to the float64 kernels.
+        float* const dst = FUSED ? crow + lag0 : s;                           // FUSED: straight into the record's row
+        const int nl = (n_lags - lag0 < SEG) ? n_lags - lag0 : SEG;
         if (__builtin_amdgcn_ballot_w64(!(emin >= 1.0e-12f && emax < 3.0e38f)) == 0) {
             #pragma unroll
-            for (int r = 0; r < R; ++r) s[lane * R + r] = (acc[r].x + acc[r].y) * __builtin_amdgcn_rsqf(en[r]);
+            for (int r = 0; r < R; ++r) if (!FUSED || lane * R + r < nl) dst[lane * R + r] = (acc[r].x + acc[r].y) * __builtin_amdgcn_rsqf(en[r]);
         } else {
             #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float q32 = (acc[r].x + acc[r].y) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(en[r]) + 1e-12f);
-                s[lane * R + r] = (en[r] < 3.0e38f) ? q32 : __builtin_nanf("");
+                if (!FUSED || lane * R + r < nl) dst[lane * R + r] = (en[r] < 3.0e38f) ? q32 : __builtin_nanf("");
             }
         }
         wave_fence_lds();
-        const int nl = (n_lags - lag0 < SEG) ? n_lags - lag0 : SEG;
-        float* cr = corr + rec * n_lags + lag0;
-        // straight-line stores (no loop): the compiler then knows how many are outstanding and waits for the
-        // NEXT record's loads with a counted vmcnt instead of draining these stores first
-        #pragma unroll
-        for (int u = 0; u < R; ++u) { const int i = lane + 64 * u; if (i < nl) cr[i] = s[i]; }
-        wave_fence_lds();
+        if constexpr (FUSED) {
+            if (lag0 + SEG >= n_lags) {                                       // last segment: the row is complete
+                PwFixed& S = *reinterpret_cast<PwFixed*>(reinterpret_cast<unsigned char*>(crow) + (((size_t)n_lags * 4 + 15) & ~(size_t)15));
+                sync_pick_row(S, crow, n_lags, fo.y64 + rec * T, tabs->tpl[bi], rec, lane, fo);
+            }
+        } else {
+            float* cr = corr + rec * n_lags + lag0;
+            // straight-line stores (no loop): the compiler then knows how many are outstanding and waits for the
+            // NEXT record's loads with a counted vmcnt instead of draining these stores first
+            #pragma unroll
+            for (int u = 0; u < R; ++u) { const int i = lane + 64 * u; if (i < nl) cr[i] = s[i]; }
+            wave_fence_lds();
+        }
     };
-    body(item);
-    for (item += (unsigned)stride; item < (unsigned)n_items; item += (unsigned)stride) body(item);
+    if constexpr (FUSED) {
+        for (; item < (unsigned)n_items; item = next_item(item)) body(item);
+    } else {
+        body(item);
+        for (item += (unsigned)stride; item < (unsigned)n_items; item += (unsigned)stride) body(item);
+    }
 }
 
 // ------------------------------------------------------------------------------------ exact value
@@ -349,6 +390,212 @@ __device__ bool pw_exact_stats(PwFixed& S, int n, int k_lo, int k_hi, double d, 
     return true;
 }
 
+__host__ __device__ __forceinline__ size_t xf_lds_per_wave(int ns2, int n_lags)
+{
+    return (size_t)((ns2 + 3) & ~3) * 4 + (((size_t)n_lags * 4 + 15) & ~(size_t)15) + sizeof(PwFixed);
+}
+
+// ------------------------------------------------------------------------------------ fused sync: threshold + peaks of one row
+// One wave, the float32 screen row c[0..n) in LDS.  Same decisions as es_pick_exact_wave_kernel (hence as the float64
+// path), reached with far fewer passes over the row in the common case:
+//   * ONE linear 256-bin histogram of the row (bins of 1/128 over [-1, 1): correlation values spread over them, so the
+//     LDS atomics hardly collide -- the radix select's first digit, sign + exponent, takes a handful of values).
+//   * Saturation test.  thr = min(med + 4.5 * 1.4826 * MAD, 0.95).  The histogram brackets the median,
+//     med >= lo(bl) - d (bl = bin of the lower middle order statistic, d = DELTA), and counts values certainly at least
+//     r_j = j/128 - 2d away from ANY median in that bracket: the bins below bl - j and above bh + j.  If at least
+//     n - k_lo values are that far out, the k_lo-th absolute deviation -- hence the MAD -- is >= r_j.  When
+//     lo(bl) - d + 6.6717 * r_j >= 0.95 + 1e-6 the minimum is 0.95 whatever the exact median and MAD are, and neither
+//     is computed.  (Band-passed noise, and clean frames too, have MAD ~0.2: the threshold saturates on every workload of
+//     BASELINE.json; records where it does not take the exact order statistics of es_pick_exact_wave_kernel.)
+//   * Threshold crossers are looked for only if the histogram has a value at or above thr - d.
+//   * Fallback (no peak): the five largest exact correlations lie among the screen values >= lo(b*) - 2d, b* = the
+//     highest bin with at least five values at or above it -- read off the histogram, no selection pass.
+// Flags (record redone by the float64 kernels): 1 non-finite screen, 2/3 order-statistic band too wide, 4 too many rivals
+// of a candidate within DELTA, 5 fallback list too long.
+__device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, const double* tpl, long long rec, int lane,
+                              const FusedArgs& fo)
+{
+    const int min_distance = ES_FRAME_LEN / 2;
+    auto flag_out = [&](int code) { if (lane == 0) { fo.flags[rec] = (uint8_t)code; if (fo.nflag) atomicAdd(fo.nflag, 1); } };
+    auto exact_corr = [&](int i) { return corr64_at(yr, i, tpl); };
+    const int k_hi = n / 2, k_lo = (n & 1) ? n / 2 : n / 2 - 1;
+    constexpr double BINW = 1.0 / 128.0;
+    constexpr double MARG = 2.5 * DELTA;                                // screen error both ways + float32 binning slack
+    uint32_t* const cum = reinterpret_cast<uint32_t*>(S.val);           // cum[b] = number of values in bins < b, b = 0..256
+
+    // ---- histogram
+    #pragma unroll
+    for (int b = 0; b < 4 * PW_HCOPIES; ++b) (&S.hist[0][0])[lane + 64 * b] = 0;
+    wave_fence_lds();
+    int bad = 0;
+    {
+        uint32_t* const myh = S.hist[lane & (PW_HCOPIES - 1)];
+        for (int i = lane; i < n; i += 64) {
+            const float v = c[i];
+            bad |= !(__builtin_fabsf(v) < 1e30f);                       // inf / nan / absurd: screen unusable
+            int b = (int)((v + 1.0f) * 128.0f);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            atomicAdd(&myh[b], 1u);
+        }
+    }
+    wave_fence_lds();
+    if (__ballot(bad)) { flag_out(1); return; }
+    uint32_t h[4];
+    #pragma unroll
+    for (int b = 0; b < 4; ++b) {                                       // lane owns four consecutive bins
+        uint32_t t = 0;
+        #pragma unroll
+        for (int cpy = 0; cpy < PW_HCOPIES; ++cpy) t += S.hist[cpy][4 * lane + b];
+        h[b] = t;
+    }
+    const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
+    uint32_t incl = s4;
+    #pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    {
+        uint32_t e = incl - s4;
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) { cum[4 * lane + b] = e; e += h[b]; }
+        if (lane == 63) cum[256] = e;
+    }
+    wave_fence_lds();
+    auto bin_of_rank = [&](int k) {                                     // the bin holding the k-th smallest screen value
+        int mine = -1;
+        uint32_t e = incl - s4;
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) { if ((int)e <= k && k < (int)(e + h[b])) mine = 4 * lane + b; e += h[b]; }
+        const unsigned long long m = __ballot(mine >= 0);
+        return __shfl(mine, __ffsll((long long)m) - 1);
+    };
+    const int bl = bin_of_rank(k_lo), bh = (k_hi == k_lo) ? bl : bin_of_rank(k_hi);
+
+    // ---- threshold
+    double thr = 0.0;
+    bool have_cum = true;
+    {
+        const int j = lane;                                             // r_j = j/128 - MARG
+        const uint32_t below = (bl - j > 0) ? cum[bl - j] : 0u;
+        const uint32_t above = (uint32_t)n - cum[(bh + j + 1 < 256) ? bh + j + 1 : 256];
+        const bool okj = (int)(below + above) >= n - k_lo;
+        const unsigned long long mk = __ballot(okj);
+        const int jmax = (~mk) ? (int)__builtin_ctzll(~mk) - 1 : 63;    // count_out is non-increasing in j: leading run of ok's
+        const double mL = (-1.0 + bl * BINW) - MARG;
+        const bool sat = bl >= 1 && bh <= 254 && jmax >= 0 && mL + (4.5 * 1.4826) * (jmax * BINW - MARG) >= 0.95 + 1e-6;
+        if (sat) {
+            thr = 0.95;
+        } else {
+            double r0, r1;
+            if (!pw_exact_stats(S, n, k_lo, k_hi, DELTA, lane, [&](int i) { return (double)c[i]; }, exact_corr, r0, r1)) { flag_out(2); return; }
+            const double med = (n & 1) ? r0 : (r0 + r1) / 2.0;
+            if (!pw_exact_stats(S, n, k_lo, k_hi, DELTA, lane, [&](int i) { return __builtin_fabs((double)c[i] - med); },
+                                [&](int i) { return __builtin_fabs(corr64_at(yr, i, tpl) - med); }, r0, r1)) { flag_out(3); return; }
+            const double mad = ((n & 1) ? r0 : (r0 + r1) / 2.0) + 1e-12;
+            thr = med + 4.5 * 1.4826 * mad;
+            if (0.95 < thr) thr = 0.95;
+            have_cum = false;                                           // the selects reused the histogram and cum[]
+        }
+    }
+
+    // ---- threshold crossers in ascending order; each one is settled exactly (as in es_pick_exact_wave_kernel)
+    int total = 0;
+    bool overflow = false;
+    bool any_cross = true;
+    if (have_cum) {                                                     // is there any value at or above thr - DELTA at all?
+        int bt = (int)(((thr - DELTA) + 1.0) * 128.0) - 1;              // one bin of slack for the float32 binning
+        bt = bt < 0 ? 0 : (bt > 255 ? 255 : bt);
+        any_cross = cum[256] - cum[bt] > 0;
+    }
+    for (int base = 0; any_cross && base < n && !overflow; base += 64) {
+        const int i = base + lane;
+        const bool cand = (i < n) && ((double)c[i] >= thr - DELTA);
+        unsigned long long m = __ballot(cand);
+        if (!m) continue;
+        const double cv_mine = cand ? corr64_at(yr, i, tpl) : 0.0;      // all candidates of the chunk at once
+        while (m && !overflow) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int ci = base + bit;
+            const double cv = __shfl(cv_mine, bit);
+            if (cv < thr) continue;
+            int lo = ci - min_distance; if (lo < 0) lo = 0;
+            int hi = ci + min_distance + 1; if (hi > n) hi = n;
+            bool bigger = false;
+            int namb = 0;
+            for (int j0 = lo; j0 < hi && !bigger; j0 += 64) {
+                const int j = j0 + lane;
+                const bool in = j < hi;
+                const double s32 = in ? (double)c[j] : 0.0;
+                const bool big = in && s32 > cv + DELTA;
+                const bool amb = in && !big && s32 >= cv - DELTA && j != ci;   // rival within reach: settle exactly
+                if (__ballot(big)) { bigger = true; break; }
+                const unsigned long long ma = __ballot(amb);
+                const int pos = namb + lanes_below(ma);
+                if (amb && pos < 64) S.list[pos] = j;
+                namb += __popcll(ma);
+            }
+            if (bigger) continue;
+            if (namb > 64) { overflow = true; break; }
+            if (namb > 0) {
+                wave_fence_lds();
+                const bool have = lane < namb;
+                const double jv = have ? corr64_at(yr, S.list[lane], tpl) : 0.0;
+                const bool beats = have && jv > cv;
+                wave_fence_lds();
+                if (__ballot(beats)) continue;
+            }
+            if (lane == 0 && total < ES_MAX_PEAKS) fo.peaks[rec * ES_MAX_PEAKS + total] = ci;
+            ++total;
+        }
+    }
+    if (overflow) { flag_out(4); return; }
+
+    if (total == 0) {
+        // ---- fallback: five largest exact correlations (descending; equal values -> higher index)
+        const int kmax = n < 5 ? n : 5;
+        double lo;
+        if (have_cum) {
+            int mine = -1;                                              // highest bin with >= kmax values at or above it
+            #pragma unroll
+            for (int b = 0; b < 4; ++b) if ((int)(cum[256] - cum[4 * lane + b]) >= kmax) mine = 4 * lane + b;
+            const unsigned long long m = __ballot(mine >= 0);
+            const int bstar = __shfl(mine, 63 - (int)__builtin_clzll(m));      // bin 0 always qualifies (n >= kmax)
+            lo = (bstar == 0) ? -1e300 : (-1.0 + bstar * BINW) - 2.0 * DELTA - 1e-6;
+        } else {
+            const float t5 = key_f32(pw_select(S, n, n - kmax, lane, [&](int i) { return f32_key(c[i]); }));
+            lo = (double)t5 - 2.0 * DELTA;
+        }
+        int nb = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool in = (i < n) && ((double)c[i] >= lo);
+            const unsigned long long mb = __ballot(in);
+            const int pos = nb + lanes_below(mb);
+            if (in && pos < PW_CAP) S.list[pos] = i;
+            nb += __popcll(mb);
+        }
+        if (nb > PW_CAP) { flag_out(5); return; }
+        wave_fence_lds();
+        for (int idx = lane; idx < nb; idx += 64) S.val[idx] = corr64_at(yr, S.list[idx], tpl);
+        wave_fence_lds();
+        for (int idx = lane; idx < nb; idx += 64) {
+            const double v = S.val[idx]; const int ii = S.list[idx];
+            int before = 0;                                             // how many sort ahead of me
+            for (int j = 0; j < nb; ++j) {
+                const double vj = S.val[j]; const int ij = S.list[j];
+                before += (vj > v) || (vj == v && ij > ii);
+            }
+            if (before < kmax) fo.peaks[rec * ES_MAX_PEAKS + before] = ii;
+        }
+        if (lane == 0) fo.npeaks[rec] = kmax | (1 << 30);
+        total = kmax;
+        wave_fence_lds();
+    } else if (lane == 0) {
+        fo.npeaks[rec] = total;
+    }
+    if (lane >= total && lane < ES_MAX_PEAKS) fo.peaks[rec * ES_MAX_PEAKS + lane] = -1;         // unused tail of the row
+    if (lane == 0) { fo.thr[rec] = thr; fo.flags[rec] = 0; }
+}
+
 __global__ __launch_bounds__(64 * PW_WAVES) void es_pick_exact_wave_kernel(const float* __restrict__ corr32,
         const double* __restrict__ y, long long B, int T, const uint8_t* __restrict__ band,
         const es_band_tables* __restrict__ tabs, double* __restrict__ thr_out, int32_t* __restrict__ peaks,
@@ -493,17 +740,17 @@ int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uin
     long long blocks = (B * nseg + XC_WAVES - 1) / XC_WAVES;
     if (blocks > cap) blocks = cap;
     if (small)
-        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_SMALL, 0>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
-                           (long long)B, T, band, ctx->d_tables, corr32);
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_SMALL, 0, false>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32, FusedArgs{});
     else if (win2k)
-        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_WINDOW, XC_T_WINDOW>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
-                           (long long)B, T, band, ctx->d_tables, corr32);
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_WINDOW, XC_T_WINDOW, false>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32, FusedArgs{});
     else if (T == ES_FRAME_LEN)
-        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, ES_FRAME_LEN>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
-                           (long long)B, T, band, ctx->d_tables, corr32);
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, ES_FRAME_LEN, false>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32, FusedArgs{});
     else
-        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, 0>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
-                           (long long)B, T, band, ctx->d_tables, corr32);
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, 0, false>), dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y32,
+                           (long long)B, T, band, ctx->d_tables, corr32, FusedArgs{});
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
@@ -515,17 +762,43 @@ int es_launch_pick_exact(es_ctx* ctx, const float* corr32, const double* y, int6
     const int n = T - (ES_PRE_L - 1);
     const size_t per_wave = sizeof(PwFixed) + (((size_t)n * 4 + 15) & ~(size_t)15);
     const size_t lds = per_wave * PW_WAVES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->pick_attr_set) {           // per context (= per device): the attribute belongs to the device's copy of the kernel
         ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_pick_exact_wave_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PW_WAVES * (sizeof(PwFixed) + PX_MAXN * 4))));
-        attr_set = true;
+        ctx->pick_attr_set = true;
     }
     long long blocks = (B + PW_WAVES - 1) / PW_WAVES;
     const long long cap = (long long)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(es_pick_exact_wave_kernel, dim3((unsigned)blocks), dim3(64 * PW_WAVES), lds, st, corr32, y, (long long)B, T,
                        band, ctx->d_tables, thr, peaks, npeaks, flags);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_OK;
+}
+
+int es_launch_sync_fused(es_ctx* ctx, const float* y32, const double* y, int64_t B, int T, const uint8_t* band, double* thr,
+                         int32_t* peaks, int32_t* npeaks, uint8_t* flags, int* nflag, hipStream_t st)
+{
+    const int n_lags = T - (ES_PRE_L - 1);
+    if (n_lags > PX_MAXN) { ctx->err = "es_sync_fused_batch: more than 4096 lags; use the float64 path"; return ES_EINVAL; }
+    const bool win2k = T == XC_T_WINDOW;
+    const int R = win2k ? XC_R_WINDOW : XC_R;
+    const long long nseg = (n_lags + 64 * R - 1) / (64 * R);
+    if ((long long)B * nseg >= (1LL << 31)) { ctx->err = "es_sync_fused_batch: batch too large for one launch"; return ES_EINVAL; }
+    const size_t lds = XF_WAVES * xf_lds_per_wave(64 * R + ES_PRE_L - 1 + 2, n_lags);
+    long long blocks = (B + XF_WAVES - 1) / XF_WAVES;
+    const long long cap = (long long)ctx->num_cu * 32;
+    if (blocks > cap) blocks = cap;
+    const FusedArgs fo{y, thr, peaks, npeaks, flags, nflag};
+    if (win2k)
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_WINDOW, XC_T_WINDOW, true>), dim3((unsigned)blocks), dim3(64 * XF_WAVES), lds, st, y32,
+                           (long long)B, T, band, ctx->d_tables, (float*)nullptr, fo);
+    else if (T == ES_FRAME_LEN)
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, ES_FRAME_LEN, true>), dim3((unsigned)blocks), dim3(64 * XF_WAVES), lds, st, y32,
+                           (long long)B, T, band, ctx->d_tables, (float*)nullptr, fo);
+    else
+        hipLaunchKernelGGL((es_xcorr32_kernel<XC_R, 0, true>), dim3((unsigned)blocks), dim3(64 * XF_WAVES), lds, st, y32,
+                           (long long)B, T, band, ctx->d_tables, (float*)nullptr, fo);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }

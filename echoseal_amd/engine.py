@@ -145,13 +145,34 @@ class RxEngine:
                   "es_pick_exact_batch")
         return thr, peaks, npeaks, flags
 
+    def sync_fused(self, y: torch.Tensor, y32: torch.Tensor, band: torch.Tensor):
+        """Correlation screen + exact threshold / peak picking in ONE kernel (the screen row never leaves LDS):
+        -> (thr, peaks, npeaks, flags), identical to pick(xcorr(y))."""
+        B, T = y.shape
+        thr = torch.empty(B, dtype=torch.float64, device=self.device)
+        peaks = torch.empty((B, nat.ES_MAX_PEAKS), dtype=torch.int32, device=self.device)
+        npeaks = torch.empty(B, dtype=torch.int32, device=self.device)
+        flags = torch.empty(B, dtype=torch.uint8, device=self.device)
+        nat.check(self._ctx, self._lib.es_sync_fused_batch(self._ctx, _ptr(y32), _ptr(y), B, T, _ptr(band), _ptr(thr), _ptr(peaks),
+                                                           _ptr(npeaks), _ptr(flags), self._stream()), "es_sync_fused_batch")
+        return thr, peaks, npeaks, flags
+
+    def reserve(self, B_max: int, T_max: int) -> None:
+        """Size the context's workspaces once (es_reserve): afterwards the sync entry points only enqueue."""
+        nat.check(self._ctx, self._lib.es_reserve(self._ctx, int(B_max), int(T_max)), "es_reserve")
+
     FAST_MAX_LAGS = 4096
 
-    def sync_fast(self, frames: torch.Tensor, band: torch.Tensor) -> SyncResult:
-        """Band-pass + float32 correlation screen + exact peak picking (results identical to sync())."""
+    def sync_fast(self, frames: torch.Tensor, band: torch.Tensor, *, fused: bool = True) -> SyncResult:
+        """Band-pass + float32 correlation screen + exact peak picking (results identical to sync()).  fused: screen and
+        picking in one kernel (the default); otherwise es_xcorr32_batch -> es_pick_exact_batch with the screen in HBM."""
         y, y32 = self.bpf2(frames, band)
-        corr32 = self.xcorr32(y32, band)
-        thr, peaks, npeaks, flags = self.pick_exact(corr32, y, band)
+        if fused:
+            corr32 = None
+            thr, peaks, npeaks, flags = self.sync_fused(y, y32, band)
+        else:
+            corr32 = self.xcorr32(y32, band)
+            thr, peaks, npeaks, flags = self.pick_exact(corr32, y, band)
         res = SyncResult(y, None, thr, peaks, npeaks)
         res.corr32, res.flags, res.y32 = corr32, flags, y32
         return res
@@ -411,7 +432,7 @@ class RxEngine:
             llr = self.llr(y, band, pn_rows, start=start, variant=0)
         if fast:
             corr = None
-            thr, peaks, npeaks, _flags = self.pick_exact(self.xcorr32(y32, band), y, band)
+            thr, peaks, npeaks, _flags = self.sync_fused(y, y32, band)
         else:
             corr = self.xcorr(y, band)
             thr, peaks, npeaks = self.pick(corr)
@@ -478,10 +499,9 @@ class DecodePipeline:
                 y, y32 = e.bpf2(frames, band)
                 if xcorr_events is not None:
                     xcorr_events[0].record()
-                corr32 = e.xcorr32(y32, band)
+                thr, peaks, npeaks, flags = e.sync_fused(y, y32, band)        # correlation screen + exact picking, one kernel
                 if xcorr_events is not None:
                     xcorr_events[1].record()
-                thr, peaks, npeaks, flags = e.pick_exact(corr32, y, band)
                 llr = e.llr(y, band, pn_rows, start=start, variant=0)
                 scl = e.scl(llr, list_size=self.list_size, skip_if_hard_ok=True)
                 done = torch.cuda.Event()
@@ -494,15 +514,14 @@ class DecodePipeline:
             self.front.wait_event(self._inflight.pop(0))
         with torch.cuda.stream(self.front):
             y, y32 = eng.bpf2(frames, band)
-            if xcorr_events is not None:
-                xcorr_events[0].record()
-            corr32 = eng.xcorr32(y32, band)
-            if xcorr_events is not None:
-                xcorr_events[1].record()
             self.side.wait_stream(self.front)
             with torch.cuda.stream(self.side):
                 llr = eng.llr(y, band, pn_rows, start=start, variant=0)
-            thr, peaks, npeaks, flags = eng.pick_exact(corr32, y, band)
+            if xcorr_events is not None:
+                xcorr_events[0].record()
+            thr, peaks, npeaks, flags = eng.sync_fused(y, y32, band)
+            if xcorr_events is not None:
+                xcorr_events[1].record()
             self.front.wait_stream(self.side)
             ready = torch.cuda.Event()
             ready.record()

@@ -65,7 +65,8 @@ int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float*
 
 /* Band-pass: y = lfilter(b, a, x.astype(float32)), zero initial state, float64 out.
  *   replaces rtwm/detector.py:59-60 (and :240-241)
- *   frames_dev [B][T] ES_DTYPE_F32 or ES_DTYPE_I16 (int16 is dequantised as x/32767)
+ *   frames_dev [B][T] ES_DTYPE_F32 or ES_DTYPE_I16 (int16 is dequantised as x/32768, what soundfile.read hands the
+ *              reference for PCM16 files, rx_app.py:26)
  *   band_dev   [B] uint8 index into the band tables
  *   y_dev      [B][T] float64                                                               */
 int es_bpf_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
@@ -81,7 +82,7 @@ int es_xcorr_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const uin
 /* Median/MAD threshold + non-maximum suppression (+ top-5 fallback):
  *   replaces rtwm/detector.py:83-99
  *   thr_dev    [B] float64
- *   peaks_dev  [B][ES_MAX_PEAKS] int32 (ascending; fallback: descending correlation)
+ *   peaks_dev  [B][ES_MAX_PEAKS] int32 (ascending; fallback: descending correlation); whole rows are written, -1 = unused
  *   npeaks_dev [B] int32: number of valid entries; bit 30 set when the fallback branch ran      */
 int es_pick_batch(es_ctx* ctx, const double* corr_dev, int64_t B, int n_lags, double* thr_dev,
                   int32_t* peaks_dev, int32_t* npeaks_dev, void* stream);
@@ -102,6 +103,25 @@ int es_xcorr32_batch(es_ctx* ctx, const float* y32_dev, int64_t B, int T, const 
 int es_pick_exact_batch(es_ctx* ctx, const float* corr32_dev, const double* y_dev, int64_t B, int T,
                         const uint8_t* band_dev, double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev,
                         uint8_t* flags_dev, void* stream);
+
+/* The same result in ONE kernel (SURVEY.md section 8d "fused with threshold + NMS and writing only peaks"): the float32
+ * correlation row of a record stays in LDS, threshold (median / MAD or the proof that it saturates at 0.95) and peaks are
+ * settled from it with float64 re-evaluation of every value near a decision, and only thr / peaks / npeaks / flags reach
+ * HBM: 4 T bytes of samples in (+ the few float64 samples the re-evaluations read), <= 150 bytes out per record.
+ * thr / peaks / npeaks bit-identical to es_xcorr_batch + es_pick_batch.  Records the screen cannot settle (flags_dev != 0:
+ * non-finite or constant data) are counted on the device and redone by the float64 kernels inside the call; with none
+ * flagged those two launches leave at once.  T - 62 <= 4096.
+ *   replaces rtwm/detector.py:76-99                                                                                  */
+int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, int64_t B, int T,
+                        const uint8_t* band_dev, double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev,
+                        uint8_t* flags_dev, void* stream);
+
+/* Size the context's float64 correlation workspace (used by es_sync_batch without corr_dev, and by the redo pass of
+ * es_pick_exact_batch / es_sync_fused_batch) for batches of up to B_max records of T_max samples.  Allocation synchronises
+ * the device: call this once, outside any stream capture; afterwards those entry points only enqueue.  Without it they
+ * grow the workspace themselves the first time a larger batch arrives (same effect as calling es_reserve there).
+ * One stream at a time per context: the workspace and the list decoder's scratch slab are shared by every call on it.   */
+int es_reserve(es_ctx* ctx, int64_t B_max, int T_max);
 
 /* Convenience: the three float64 calls above back to back (workspace owned by the context). */
 int es_sync_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T,
@@ -140,7 +160,7 @@ int es_header_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const in
  *   hard_info_dev   [B][55], hard_ok_dev [B]
  *   cand_info_dev   [B][L][55] candidates in ascending path-metric (stable) order
  *   cand_metric_dev [B][L] float64, cand_ok_dev [B][L] CRC flags
- *   ncand_dev       [B] int32: L, or 0 when the list loop was skipped                         */
+ *   ncand_dev       [B] int32: L, or 0 when the list loop was skipped (the record's candidate rows then read as zeros) */
 int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int list_size,
                  int skip_if_hard_ok, uint8_t* hard_info_dev, uint8_t* hard_ok_dev,
                  uint8_t* cand_info_dev, double* cand_metric_dev, uint8_t* cand_ok_dev,

@@ -794,3 +794,51 @@ def test_device_softplus_bits(engine, oracle):
     idx = rng.integers(0, t.size, 20000)
     ref = np.array([log1p_(exp_(float(v))) for v in t[idx]])
     assert np.array_equal(got[idx].view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("T", [1215, 2048, 700, 63, 64, 190, 3000, 4158])
+def test_sync_fused_equals_float64_path(engine, T):
+    """es_sync_fused_batch (screen row in LDS, histogram shortcuts) == es_xcorr_batch + es_pick_batch, bit for bit:
+    clean frames, noisy frames, pure noise, low-level noise (threshold does not saturate), silence, constants, spikes."""
+    rng = np.random.default_rng(T)
+    B = 160
+    frames, band, _ = _workload(B)
+    x = np.zeros((B, T), np.float32)
+    m = min(T, 1215)
+    x[:, :m] = frames[:, :m]
+    x[32:64] += rng.normal(0, 0.05, (32, T)).astype(np.float32)                 # noisy frames
+    x[64:96] = rng.normal(0, 0.3, (32, T)).astype(np.float32)                   # pure noise
+    if T >= 400:
+        x[96:112] = 0.0; x[96:112, 50:50 + min(m, T - 50)] = frames[96:112, :min(m, T - 50)]   # frame at an offset, silence around it
+        x[112:120] = (1e-3 * rng.normal(0, 1, (8, T))).astype(np.float32); x[112:120, :m] += frames[112:120, :m]
+    x[120:124] = 0.0                                                            # digital silence -> flagged, float64 redo
+    x[124:128] = 0.25                                                           # constant
+    x[128:132] = 0.0; x[128:132, T // 2] = 1.0                                  # one spike
+    x[132:140] = np.round(rng.normal(0, 2, (8, T))).astype(np.float32)          # coarse integers: many exact ties
+    x[140:150] = (1e-20 * rng.normal(0, 1, (10, T))).astype(np.float32)         # tiny amplitudes
+    x[150:160] = (1e15 * rng.normal(0, 1, (10, T))).astype(np.float32)          # huge amplitudes
+    f, b = _dev(engine, x, band)
+    want = engine.sync(f, b, keep_corr=False)
+    y, y32 = engine.bpf2(f, b)
+    thr, peaks, npeaks, flags = engine.sync_fused(y, y32, b)
+    assert torch.equal(thr, want.thr) and torch.equal(npeaks, want.npeaks)
+    n = (want.npeaks & 0xFFFF).clamp(max=32)
+    mask = torch.arange(32, device=engine.device)[None, :] < n[:, None]
+    assert torch.equal(torch.where(mask, peaks, -1), torch.where(mask, want.peaks, -1))
+    assert torch.all(peaks[~mask] == -1)
+    if T >= 1215:                                                               # ordinary records never need the float64 redo
+        assert int(flags[32:96].sum()) == 0                                     # (clean frames padded with digital silence do:
+        assert T > 1215 or int(flags[:32].sum()) == 0                           #  hundreds of exactly equal correlations)
+
+
+def test_sync_fused_full_size_properties(engine):
+    """65 536 config-3 windows: fused == unfused (es_xcorr32_batch + es_pick_exact_batch) on every record."""
+    from echoseal_amd import workloads as WL
+    fr, _ = engine.synthetic_frames(KEY, 0, 16384)
+    win, off = WL.c3_windows_device(fr.repeat(4, 1))
+    sec_band = engine.schedule(WatermarkEmbedder(KEY).sec._prng.sub_key, KEY, ctr0=0, n=16384)[1].repeat(4)
+    y, y32 = engine.bpf2(win, sec_band)
+    a = engine.sync_fused(y, y32, sec_band)
+    b = engine.pick_exact(engine.xcorr32(y32, sec_band), y, sec_band)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
