@@ -53,6 +53,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 KEY = b"\xAA" * 32
 XCORR_BYTES_PER_FRAME = 4 * 1215 + 4 * (1215 - 62)        # 9 472 B
 XCORR_BYTES_PER_WINDOW = 4 * 2048 + 4 * (2048 - 62)       # 16 136 B
+FUSED_BYTES_PER_FRAME = 4 * 1215 + 150                      # fused sync: samples in, thr / peaks / npeaks / flag out
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8.0 TB/s spec
 # FP64 vector issue peak: 78.6 TFLOP/s (spec) = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz, i.e. one wave64
 # FP64-class instruction per 4 cycles and SIMD -> 1024 SIMDs x 0.6 G = 614.4 G wave-instructions/s
@@ -76,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on fewer GPUs)")
     ap.add_argument("--scl-streams", type=int, default=2, help="list-decoder streams (= batches in flight) of the pipeline")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: = --scl-streams)")
+    ap.add_argument("--no-side-stream", action="store_true", help="front-end / list-decoder arrangement: LLR on the front-end stream")
     ap.add_argument("--lanes", type=int, default=7, help="pipeline as K independent whole-chain lanes (0: front end + list-decoder streams)")
     ap.add_argument("--scl-multi", type=int, default=1, help="es_set_option scl_multi for the pipelined headline: -1 auto, 0 one frame per wave, 1 several")
     return ap.parse_args(argv)
@@ -219,7 +221,7 @@ def run_rank(a) -> None:
     # A step = one batch through the whole hot path.  Batches are independent, so the engine's streaming pipeline
     # (echoseal_amd.engine.DecodePipeline) keeps two in flight: the front end of batch k+2 starts when batch k leaves,
     # beside the list decoder of batch k+1.  Every step's outputs are complete at the final sync.
-    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None, lanes=a.lanes)
+    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None, lanes=a.lanes, side_stream=not a.no_side_stream)
     for e in pipe.scl_engs:
         e.set_option("scl_multi", a.scl_multi)
 
@@ -252,7 +254,7 @@ def run_rank(a) -> None:
     out_legs = {}
 
     # ============================================================ leg c3 (one GPU): 65 536 jittered / noisy windows
-    roof_c3 = None
+    roof_c3 = roof_fused = None
     if "c3" in legs and world == 1:
         Bw = a.c3_windows
         parts, pays = [], []
@@ -266,14 +268,18 @@ def run_rank(a) -> None:
         ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.c3_steps)]
         stage = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(a.c3_steps)]
 
-        def c3_step(k=None):
+        def c3_step(k=None, fused=True):
             st = stage[k] if k is not None else None
             if st: st[0].record()
             y, y32 = eng.bpf2(win, band3)
             if st: st[1].record(); ev3[k][0].record()
-            c32 = eng.xcorr32(y32, band3)
-            if st: ev3[k][1].record(); st[2].record()
-            thr, pk, npk, flags = eng.pick_exact(c32, y, band3)
+            if fused:                                            # correlation screen + exact picking in one kernel
+                thr, pk, npk, flags = eng.sync_fused(y, y32, band3)
+                if st: ev3[k][1].record(); st[2].record()
+            else:                                                # the screen through HBM: es_xcorr32_batch -> es_pick_exact_batch
+                c32 = eng.xcorr32(y32, band3)
+                if st: ev3[k][1].record(); st[2].record()
+                thr, pk, npk, flags = eng.pick_exact(c32, y, band3)
             if st: st[3].record()
             start = pk[:, 0].clamp(min=0).contiguous()
             llr = eng.llr(y, band3, pn3, start=start)
@@ -284,31 +290,52 @@ def run_rank(a) -> None:
             if st: st[6].record()
             return pk, npk, flags, payload, ok
 
-        c3_step(); torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(a.c3_steps):
-            pk, npk, flags, payload, ok = c3_step(k)
-        barrier()
-        dt3 = time.perf_counter() - t0
-        x_ms = float(np.mean([s.elapsed_time(e) for s, e in ev3]))
-        names = ("bpf", "xcorr32", "pick_exact", "llr", "scl", "select")
-        stage_ms = {n: float(np.mean([st[i].elapsed_time(st[i + 1]) for st in stage])) for i, n in enumerate(names)}
+        def c3_run(fused, steps):
+            c3_step(fused=fused); torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                res3 = c3_step(k, fused=fused)
+            barrier()
+            dt3 = time.perf_counter() - t0
+            x_ms = float(np.mean([s.elapsed_time(e) for s, e in ev3[:steps]]))
+            names = ("bpf", "sync_fused" if fused else "xcorr32", "(in sync_fused)" if fused else "pick_exact", "llr", "scl", "select")
+            stage_ms = {n: float(np.mean([st[i].elapsed_time(st[i + 1]) for st in stage[:steps]])) for i, n in enumerate(names)}
+            return dt3, x_ms, stage_ms, res3
+
+        wl3 = (f"C3: {Bw} windows of 2048 float32 samples, one frame each (ctr = i, resampled by U[0.95,1.05] with linear interpolation, uniform "
+               f"offset, AWGN at -15 dB SNR), generated on the device; band-pass -> float32 NCC screen + exact median/MAD threshold + NMS/top-5 "
+               f"-> _llr at the detected peak -> SCL-{L} -> selection")
+        dt3, xf_ms, stage_ms, (pk, npk, flags, payload, ok) = c3_run(True, a.c3_steps)
         found = int(((pk[:, :5] - off[:, None]).abs() <= 2).any(dim=1).sum().item())
-        ach = XCORR_BYTES_PER_WINDOW * Bw / (x_ms * 1e-3) / 1e9
-        pmc = (_profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch", {})
-        roof_c3 = {"kernel": "es_xcorr32_kernel<17,2048>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch") if Bw == 65536 else None,
-                   "traffic_source": "rocprofv3 --pmc passes committed as profiles/r02_xcorr32_pmc_traffic.json (same launch shape; not re-measured by this run)",
-                   "launch_ms": x_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_WINDOW * Bw,
-                   "where": f"HIP events around the launch inside the timed c3 leg ({a.c3_steps} steps)"}
-        out_legs["c3"] = {"workload": f"C3: {Bw} windows of 2048 float32 samples, one frame each (ctr = i, resampled by U[0.95,1.05] with linear "
-                                      f"interpolation, uniform offset, AWGN at -15 dB SNR), generated on the device; band-pass -> float32 NCC screen -> "
-                                      f"exact median/MAD threshold + NMS/top-5 -> _llr at the detected peak -> SCL-{L} -> selection",
+        achf = (4 * 2048 + 150) * Bw / (xf_ms * 1e-3) / 1e9
+        roof_fused = {"kernel": "es_xcorr32_kernel<17,2048,FUSED> (es_sync_fused_batch: screen row kept in LDS, threshold and peaks settled in the same kernel)",
+                      "bound": "hbm", "achieved": achf, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achf / HBM_PEAK_GBS, "traffic": None,
+                      "launch_ms": xf_ms, "algorithmic_bytes_per_launch": (4 * 2048 + 150) * Bw,
+                      "note": "8 192 B of samples in + <= 150 B out per window (SURVEY 8d fused figure); this kernel is bound by LDS passes and "
+                              "float64 re-evaluations, not by HBM -- it exists to take 2 x 7 944 B per window of screen traffic and two launches away",
+                      "where": f"HIP events around the launch inside the timed c3 leg ({a.c3_steps} steps)"}
+        out_legs["c3"] = {"workload": wl3 + " [sync: es_sync_fused_batch]",
                           "value": Bw * a.c3_steps / dt3, "unit": "windows/s", "steps": a.c3_steps, "ms_per_step": 1e3 * dt3 / a.c3_steps,
                           "stage_ms": stage_ms, "float64_redo_records": int(flags.sum().item()),
                           "windows_with_a_top5_peak_within_2_samples_of_the_true_offset": found,
                           "fallback_records": int(((npk >> 30) & 1).sum().item())}
+        # the same pass with the screen going through HBM (es_xcorr32_batch + es_pick_exact_batch): the leg `roofline` is taken from
+        nu = max(2, min(3, a.c3_steps))
+        dtu, x_ms, stage_u, (pk2, npk2, flags2, payload2, ok2) = c3_run(False, nu)
+        same = bool(torch.equal(pk, pk2) and torch.equal(npk, npk2) and torch.equal(payload, payload2) and torch.equal(ok, ok2))
+        ach = XCORR_BYTES_PER_WINDOW * Bw / (x_ms * 1e-3) / 1e9
+        pmc = (_profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch", {})
+        roof_c3 = {"kernel": "es_xcorr32_kernel<17,2048> (es_xcorr32_batch: the stand-alone correlation kernel north_star grades against HBM)",
+                   "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch") if Bw == 65536 else None,
+                   "traffic_source": "rocprofv3 --pmc passes committed as profiles/r02_xcorr32_pmc_traffic.json (same launch shape; not re-measured by this run)",
+                   "launch_ms": x_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_WINDOW * Bw,
+                   "where": f"HIP events around the launch inside the timed c3_unfused leg ({nu} steps)"}
+        out_legs["c3_unfused"] = {"workload": wl3 + " [sync: es_xcorr32_batch + es_pick_exact_batch, screen through HBM]",
+                                  "value": Bw * nu / dtu, "unit": "windows/s", "steps": nu, "ms_per_step": 1e3 * dtu / nu, "stage_ms": stage_u,
+                                  "results_identical_to_c3": same}
+        del pk2, npk2, flags2, payload2, ok2
         del win, off, pn3, band3, pk, npk, flags, payload, ok
         torch.cuda.empty_cache()
 
@@ -374,7 +401,7 @@ def run_rank(a) -> None:
         out_legs["c5"] = c5_leg(eng, a, torch, np, WL)
 
     if rank == 0:
-        achieved = XCORR_BYTES_PER_FRAME * B / (xcorr_ms * 1e-3) / 1e9
+        achieved = FUSED_BYTES_PER_FRAME * B / (xcorr_ms * 1e-3) / 1e9
         out = {
             "metric": "watermark frames/sec decoded (sync+LLR+SCL-8) @ 48 kHz",
             "value": total * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
@@ -392,13 +419,14 @@ def run_rank(a) -> None:
                        "sync_offsets_ok": ok_sync, "frames_through_list_decoder": listed},
             "legs": out_legs,
         }
-        c2_roof = {"kernel": "es_xcorr32_kernel<5,0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        c2_roof = {"kernel": "es_xcorr32_kernel<19,1215,FUSED> (es_sync_fused_batch on the 1 024-record launch)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": xcorr_ms,
-                   "algorithmic_bytes_per_launch": XCORR_BYTES_PER_FRAME * B,
-                   "where": "HIP events around the launch inside the timed headline steps (event to event, launch gaps included); "
-                            "a 9.7 MB launch is latency-bound and served from L2 / Infinity Cache"}
+                   "algorithmic_bytes_per_launch": FUSED_BYTES_PER_FRAME * B,
+                   "where": "HIP events around the launch inside the timed headline steps (event to event, beside resident list decoders); "
+                            "a 5 MB launch is latency-bound and served from L2 / Infinity Cache"}
         if roof_c3 is not None:
             out["roofline"] = roof_c3
+            out["roofline_fused"] = roof_fused
             out["roofline_c2"] = c2_roof
         else:
             out["roofline"] = c2_roof

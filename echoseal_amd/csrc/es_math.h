@@ -215,7 +215,11 @@ ES_HD double es_div_normal(double n, double d)
 #define ES_LOGE2 0.693147180559945309417232121458176568
 
 /* softplus of a non-positive argument: log1p(exp(t)), t = -|d|  -- generic (branchy) form */
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline)) static double es_softplus_neg_generic(double t, const uint64_t* tab) { return es_log1p(es_exp(t, tab)); }
+#else
 ES_HD double es_softplus_neg_generic(double t, const uint64_t* tab) { return es_log1p(es_exp(t, tab)); }
+#endif
 
 /* Straight-line (branch-free) evaluation of the same value for the common range
  *     2^-54 <= |t| < 512  and  log1p not in its |f| < 2^-20 corner,

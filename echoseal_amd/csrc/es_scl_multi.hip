@@ -46,12 +46,14 @@ struct MWave {
     double   alphaS[MNP][MROW];
     double   candm[2 * MNP];                       // frame fr: [2*L*fr, 2*L*(fr+1))
     uint32_t betaL[MNP][32];                       // left-sibling partial sums, block of S bits at bit S
-    uint32_t curb[MNP][16];
+    union {                                        // curb lives inside the bit loop, outb before and after it
+        uint32_t curb[MNP][16];
+        uint8_t  outb[MNP][56];
+    };
     uint32_t hardw[32];
     uint32_t tbw[MWIN][MNP];                       // trace-back by windows of 32 information bits: the window's bits (first = MSB) ...
     uint8_t  tba[MWIN][MNP];                       // ... and the path (within the frame) this path descended from at the window's start
     uint8_t  sel[MNP];
-    uint8_t  outb[MNP][56];
 };
 
 template <int L>

@@ -456,7 +456,8 @@ class DecodePipeline:
     At most `depth` (= scl_streams) batches are in flight.  Results are complete after `wait(result)` / `synchronize()`;
     values are those of decode_batch (same kernels, same order per batch)."""
 
-    def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None, lanes: int = 0):
+    def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None, lanes: int = 0,
+                 side_stream: bool = True):
         self.eng = eng
         self.list_size = int(list_size)
         dev = eng.device
@@ -474,7 +475,7 @@ class DecodePipeline:
             return
         # the short front-end kernels get dispatch priority over the long-running list decoders
         self.front = torch.cuda.Stream(dev, priority=-1)
-        self.side = torch.cuda.Stream(dev, priority=-1)
+        self.side = torch.cuda.Stream(dev, priority=-1) if side_stream else self.front   # one hardware queue less without it
         self.backs = [torch.cuda.Stream(dev) for _ in range(max(1, int(scl_streams)))]
         self.scl_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in self.backs[1:]]
         # Batches in flight = list-decoder streams: the front end of batch k waits for batch k-2 to leave, so it
@@ -514,7 +515,8 @@ class DecodePipeline:
             self.front.wait_event(self._inflight.pop(0))
         with torch.cuda.stream(self.front):
             y, y32 = eng.bpf2(frames, band)
-            self.side.wait_stream(self.front)
+            if self.side is not self.front:
+                self.side.wait_stream(self.front)
             with torch.cuda.stream(self.side):
                 llr = eng.llr(y, band, pn_rows, start=start, variant=0)
             if xcorr_events is not None:
@@ -522,7 +524,8 @@ class DecodePipeline:
             thr, peaks, npeaks, flags = eng.sync_fused(y, y32, band)
             if xcorr_events is not None:
                 xcorr_events[1].record()
-            self.front.wait_stream(self.side)
+            if self.side is not self.front:
+                self.front.wait_stream(self.side)
             ready = torch.cuda.Event()
             ready.record()
         j = self._k % len(self.backs)

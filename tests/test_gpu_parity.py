@@ -404,13 +404,14 @@ def test_sync_fast_equals_float64_path(engine, oracle):
     for name, xx in cases.items():
         f, b = _dev(engine, xx.astype(np.float32), bnd)
         ref = engine.sync(f, b, keep_corr=True)
-        fast = engine.sync_fast(f, b)
-        assert torch.equal(ref.y, fast.y) and torch.equal(fast.y.to(torch.float32), fast.y32)
-        assert torch.equal(ref.thr, fast.thr), f"{name}: threshold differs"
-        assert torch.equal(ref.npeaks, fast.npeaks), f"{name}: peak count / fallback flag differs"
         k = (ref.npeaks & 0xFFFF).clamp(max=32)
-        for i in range(xx.shape[0]):
-            assert torch.equal(ref.peaks[i, :k[i]], fast.peaks[i, :k[i]]), (name, i)
+        for fused in (True, False):                 # one kernel (screen row in LDS) / screen through HBM
+            fast = engine.sync_fast(f, b, fused=fused)
+            assert torch.equal(ref.y, fast.y) and torch.equal(fast.y.to(torch.float32), fast.y32)
+            assert torch.equal(ref.thr, fast.thr), f"{name}: threshold differs"
+            assert torch.equal(ref.npeaks, fast.npeaks), f"{name}: peak count / fallback flag differs"
+            for i in range(xx.shape[0]):
+                assert torch.equal(ref.peaks[i, :k[i]], fast.peaks[i, :k[i]]), (name, i, fused)
         err = (fast.corr32.double() - ref.corr).abs()
         ok_rows = torch.isfinite(fast.corr32).all(dim=1)
         assert float(err[ok_rows].max()) < 1e-5, float(err[ok_rows].max())            # well inside DELTA = 3e-5
@@ -842,3 +843,59 @@ def test_sync_fused_full_size_properties(engine):
     b = engine.pick_exact(engine.xcorr32(y32, sec_band), y, sec_band)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def _decode_chunks(engine, frames, band, pn, chunk):
+    outs = []
+    for c0 in range(0, frames.shape[0], chunk):
+        sy, llr, scl = engine.decode_batch(frames[c0:c0 + chunk], band[c0:c0 + chunk], pn[c0:c0 + chunk], list_size=8)
+        payload, ok, which = engine.select(scl)
+        outs.append((sy.peaks[:, 0].clone(), sy.npeaks.clone(), sy.thr.clone(), payload, ok, llr[:, ::64].clone()))
+    return [torch.cat(t) for t in zip(*outs)]
+
+
+def test_c4_shard_131072_properties(engine, oracle):
+    """One BASELINE config-4 shard (2^20 frames / 8 GPUs = 131 072 clean frames, ctr 524288..): every frame syncs at
+    offset 0 with the saturated threshold; results do not depend on how the shard is cut into launches; sampled frames
+    equal the CPU oracle bit for bit (sync, LLR, SCL-8 list)."""
+    n, c0 = 131072, 524288
+    tx = WatermarkEmbedder(KEY)
+    frames = torch.cat([engine.synthetic_frames(KEY, c0 + k, 32768)[0] for k in range(0, n, 32768)])
+    pn, band = engine.schedule(tx.sec._prng.sub_key, KEY, ctr0=c0, n=n)
+    a = _decode_chunks(engine, frames, band, pn, 131072)
+    b = _decode_chunks(engine, frames, band, pn, 40000)             # ragged chunks
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    peak0, npk, thr, payload, ok, _ = a
+    assert bool((peak0 == 0).all()) and bool((thr == 0.95).all()) and bool(((npk & 0xFFFF) >= 1).all())
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    fh = frames.cpu().numpy(); bh = band.cpu().numpy(); ph = pn.cpu().numpy()
+    sy, llr, _ = engine.decode_batch(frames[:64 * 2048:2048].contiguous(), band[:64 * 2048:2048].contiguous(), pn[:64 * 2048:2048].contiguous(), list_size=8)
+    res = engine.scl(llr, list_size=8, skip_if_hard_ok=False)
+    for j in range(0, 64, 9):
+        i = j * 2048
+        o = oracle.decode_frame(fh[i], ba[bh[i]], tpl[bh[i]], taps[bh[i], :ntaps[bh[i]]], np.unpackbits(ph[i])[:1215], L=8)
+        assert np.array_equal(o["llr"], llr[j].cpu().numpy()) and o["thr"] == float(sy.thr[j])
+        nn, ci, cm, cc = oracle.scl_list(o["llr"].astype(np.float64), 8)
+        assert np.array_equal(np.packbits(ci, axis=1), res.cand_info[j].cpu().numpy()) and np.array_equal(cm, res.cand_metric[j].cpu().numpy())
+
+
+def test_c4_full_2pow20_properties(engine):
+    """All 2^20 frames of BASELINE config 4 on one GPU (frames made on the device, 131 072 per launch): sync offset 0 and
+    saturated threshold everywhere, and a second pass over a differently cut stream gives identical payloads / flags."""
+    n = 1 << 20
+    tx = WatermarkEmbedder(KEY)
+    frames = torch.empty((n, 1215), dtype=torch.float32, device=engine.device)
+    for k in range(0, n, 65536):
+        frames[k:k + 65536] = engine.synthetic_frames(KEY, k, 65536)[0]
+    pn, band = engine.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=n)
+    peak0, npk, thr, payload, ok, llr_s = _decode_chunks(engine, frames, band, pn, 131072)
+    assert bool((peak0 == 0).all()) and bool((thr == 0.95).all())
+    assert int(ok.numel()) == n and bool(torch.isfinite(llr_s).all()) and float(llr_s.abs().max()) <= 12.0
+    lo, hi = 300000, 300000 + 98304                                 # a window that straddles launch boundaries of the first pass
+    again = _decode_chunks(engine, frames[lo:hi], band[lo:hi], pn[lo:hi], 98304)
+    assert torch.equal(again[3], payload[lo:hi]) and torch.equal(again[4], ok[lo:hi]) and torch.equal(again[5], llr_s[lo:hi])
+    # the band of a counter is the device schedule's: equal to the host HMAC for sampled counters
+    from echoseal_amd.utils import band_index
+    for c in (0, 1, 65535, 65536, 999_999, n - 1):
+        assert int(band[c]) == band_index(KEY, c)
