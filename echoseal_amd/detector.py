@@ -73,18 +73,118 @@ class WatermarkDetector:
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(self.engine.device)
 
     # ------------------------------------------------------------------ API
-    def verify(self, audio: np.ndarray, fs_in: int) -> bool:
+    def _conditioned(self, audio, fs_in: int) -> np.ndarray:
         audio = np.asarray(audio)
         if fs_in != self.fs_target and audio.ndim == 1 and audio.size:
             # polyphase resampling on the device (es_resample_batch): the values scipy.signal.resample_poly returns
-            signal = self.engine.resample(audio, fs_in, self.fs_target).cpu().numpy()
-        else:
-            signal, _ = resample_to(self.fs_target, audio, fs_in)
+            return self.engine.resample(audio, fs_in, self.fs_target).cpu().numpy()
+        signal, _ = resample_to(self.fs_target, audio, fs_in)
+        return signal
+
+    def _band_order(self):
         hop0 = choose_band(self._band_key, 0)
-        if self._scan_band_multi_frame(signal, hop0):
-            return True
-        for band in [b for b in BAND_PLAN if b != hop0]:
-            if self._scan_band_multi_frame(signal, band):
+        return [hop0] + [b for b in BAND_PLAN if b != hop0]                 # rtwm/detector.py:46-52
+
+    def verify(self, audio: np.ndarray, fs_in: int) -> bool:
+        return self.verify_batch([audio], fs_in)[0]
+
+    def verify_batch(self, clips, fs_in) -> list[bool]:
+        """verify() for several recordings ("full batched verify()"): the result, the order of tries
+        and the evolution of `session_nonce` are those of calling the reference's verify() on the clips one after the other
+        (rtwm/detector.py:44-53, 105-152); what is batched is the GPU work.  Per group of equally long clips: ONE sync launch
+        sequence over (clips x 4 bands) records and ONE header decode over every peak that can hold a frame; then, clip
+        by clip and band by band in the reference's order, ONE demodulate + list-decode + validate batch over all
+        (peak, counter) candidates of the band, walked on the host with the reference's early return."""
+        fs_list = list(fs_in) if isinstance(fs_in, (list, tuple)) else [fs_in] * len(clips)
+        signals = [np.asarray(self._conditioned(c, f)).astype(np.float32, copy=False).reshape(-1) for c, f in zip(clips, fs_list)]
+        order = self._band_order()
+        scans: list = [None] * len(signals)
+        groups: dict[int, list[int]] = {}
+        for i, sgl in enumerate(signals):
+            groups.setdefault(sgl.size, []).append(i)
+        for size, idx in groups.items():
+            if size < PRE_L:                                                # rtwm/detector.py:71-73
+                continue
+            for i, sc in zip(idx, self._scan_prepare([signals[i] for i in idx], order)):
+                scans[i] = sc
+        out = []
+        for i in range(len(signals)):
+            ok = False
+            if scans[i] is not None:
+                for bi in range(len(order)):
+                    if self._scan_decide(scans[i], bi):
+                        ok = True
+                        break
+            out.append(ok)
+        return out
+
+    # one scan = what _scan_band_multi_frame needs for every band of one clip, produced in batched launches
+    def _scan_prepare(self, signals: list, bands: list) -> list:
+        import torch
+        eng = self.engine
+        g, nb, M = len(signals), len(bands), signals[0].size
+        x = self._dev(np.repeat(np.stack(signals), nb, axis=0), np.float32)            # row = clip * nb + band
+        bid = self._dev(np.tile(np.array([self._band_id(b) for b in bands]), g), np.uint8)
+        sy = eng.sync_fast(x, bid) if M - (PRE_L - 1) <= eng.FAST_MAX_LAGS else eng.sync(x, bid, keep_corr=False)
+        npk = (sy.npeaks.cpu().numpy() & 0xFFFF)
+        pk = sy.peaks.cpu().numpy()
+        rows, starts = [], []
+        for r in range(g * nb):
+            for st in pk[r, :min(int(npk[r]), pk.shape[1], PEAK_LIMIT)]:
+                if st + FRAME_LEN <= M:                                     # rtwm/detector.py:112-113
+                    rows.append(r); starts.append(int(st))
+        frames = None
+        hdr = (np.zeros(0, bool), np.zeros(0, np.int64), np.zeros(0))
+        if rows:
+            rt = torch.tensor(rows, device=eng.device)
+            cols = torch.tensor(starts, device=eng.device)[:, None] + torch.arange(FRAME_LEN, device=eng.device)[None, :]
+            frames = sy.y[rt[:, None], cols].contiguous()                  # [P, 1215] float64: y[start : start + 1215]
+            okh, val, score = eng.header(frames, bid[rt].contiguous(),
+                                         self._dev(np.packbits(self.sec.pn_bits(0, HDR_L)).reshape(1, -1), np.uint8))
+            hdr = (okh.cpu().numpy().astype(bool), val.cpu().numpy().astype(np.int64), score.cpu().numpy().astype(np.float64))
+        rows_a = np.array(rows, np.int64)
+        return [{"bands": bands, "frames": frames, "rows": rows_a - c * nb, "sel": np.flatnonzero((rows_a // nb) == c) if rows else np.zeros(0, np.int64),
+                 "starts": np.array(starts, np.int64), "hdr": hdr} for c in range(g)]
+
+    def _scan_decide(self, scan, bi: int) -> bool:
+        """The per-band loop of _scan_band_multi_frame (rtwm/detector.py:105-152) over prepared peaks / headers."""
+        band = scan["bands"][bi]
+        sel = [int(j) for j in scan["sel"] if scan["rows"][j] == bi]       # this band's peaks, in peak order
+        plan: list[tuple[int, int, int]] = []                               # (peak slot j, start, ctr) in the reference's try order
+        hdr_log = []
+        tried = 0
+        for j in sel:
+            if tried >= MAX_TRIES:
+                break
+            start = int(scan["starts"][j])
+            ctr_est = int(round(start / FRAME_LEN))
+            hdr_ok, ctr_lo16, score = bool(scan["hdr"][0][j]), int(scan["hdr"][1][j]), float(scan["hdr"][2][j])
+            hdr_log.append((float(hdr_ok), float(ctr_lo16), score))
+            cands: list[int] = []
+            if hdr_ok:                                                      # rtwm/detector.py:122-127
+                for ctr in range(max(0, ctr_est - WIDE_DELTA), ctr_est + WIDE_DELTA + 1):
+                    if (ctr & 0xFFFF) == ctr_lo16 and choose_band(self._band_key, ctr) == band:
+                        cands.append(ctr)
+            else:                                                           # :131-140
+                for ctr in range(max(0, ctr_est - TIGHT_DELTA), ctr_est + TIGHT_DELTA + 1):
+                    if choose_band(self._band_key, ctr) == band:
+                        cands.append(ctr)
+                if not cands:
+                    for ctr in range(max(0, ctr_est - WIDE_DELTA), ctr_est + WIDE_DELTA + 1):
+                        if choose_band(self._band_key, ctr) == band:
+                            cands.append(ctr)
+            for ctr in cands[:MAX_TRIES - tried]:
+                plan.append((j, start, ctr))
+            tried += len(cands[:MAX_TRIES - tried])
+        if self._hdr_trace is not None:
+            self._hdr_trace.extend(hdr_log)
+        if not plan:
+            return False
+        results = self._decode_pairs(scan["frames"], [p[0] for p in plan], [p[2] for p in plan])
+        for (j, start, ctr), blobs in zip(plan, results):
+            if self._trace is not None:
+                self._trace.append((int(band[0]), int(start), int(ctr)))
+            if self._accept(blobs, ctr):
                 return True
         return False
 
@@ -126,43 +226,10 @@ class WatermarkDetector:
         return sy.y[0].cpu().numpy(), float(sy.thr[0].item()), peaks
 
     def _scan_band_multi_frame(self, signal: np.ndarray, band) -> bool:
-        got = self._sync(signal, band)
-        if got is None:
+        sig = np.asarray(signal).astype(np.float32, copy=False).reshape(-1)
+        if sig.size < PRE_L:                                   # rtwm/detector.py:71-73
             return False
-        y, _thr, peaks = got
-        tried = 0
-        for start in peaks[:PEAK_LIMIT]:
-            if start + FRAME_LEN > y.size:
-                continue
-            frame = y[start:start + FRAME_LEN]
-            ctr_est = int(round(start / FRAME_LEN))
-            hdr_ok, ctr_lo16, _score = self._decode_header(frame, band)
-            if self._hdr_trace is not None:
-                self._hdr_trace.append((float(hdr_ok), float(ctr_lo16), float(_score)))
-            cands: list[int] = []
-            if hdr_ok:                                     # rtwm/detector.py:122-127
-                for ctr in range(max(0, ctr_est - WIDE_DELTA), ctr_est + WIDE_DELTA + 1):
-                    if (ctr & 0xFFFF) == ctr_lo16 and choose_band(self._band_key, ctr) == band:
-                        cands.append(ctr)
-            else:                                          # :131-140
-                for ctr in range(max(0, ctr_est - TIGHT_DELTA), ctr_est + TIGHT_DELTA + 1):
-                    if choose_band(self._band_key, ctr) == band:
-                        cands.append(ctr)
-                if not cands:
-                    for ctr in range(max(0, ctr_est - WIDE_DELTA), ctr_est + WIDE_DELTA + 1):
-                        if choose_band(self._band_key, ctr) == band:
-                            cands.append(ctr)
-            budget = MAX_TRIES - tried
-            results = self._decode_candidates(frame, cands[:budget])
-            for ctr, blobs in zip(cands, results):
-                if self._trace is not None:
-                    self._trace.append((int(band[0]), int(start), int(ctr)))
-                if self._accept(blobs, ctr):
-                    return True
-                tried += 1
-                if tried >= MAX_TRIES:
-                    return False
-        return False
+        return self._scan_decide(self._scan_prepare([sig], [band])[0], 0)
 
     # ------------------------------------------------------------------ demod + FEC (GPU)
     def _matched_filter_taps(self, band):
@@ -206,10 +273,17 @@ class WatermarkDetector:
     def _decode_candidates(self, frame: np.ndarray, ctrs) -> list[list[bytes | None]]:
         """For every counter: the four polar decodes the reference tries in order
         (+llr0, -llr0, +llr1, -llr1; rtwm/detector.py:161-190), each None or a 55-byte blob."""
-        from .engine import select_payload
         ctrs = list(ctrs)
         if not ctrs:
             return []
+        frames = self._dev(np.asarray(frame, dtype=np.float64).reshape(1, -1), np.float64)
+        return self._decode_pairs(frames, [0] * len(ctrs), ctrs)
+
+    def _decode_pairs(self, frames, rows, ctrs) -> list[list[bytes | None]]:
+        """The same for (frame, counter) pairs: frames = device tensor [P, <=1215] float64, pair i = (frames[rows[i]], ctrs[i]).
+        One batch: two demodulations (PN variants 0 / 1), one list decode of the 4 B sign / variant combinations, one
+        validation + selection (es_select_batch with the AEAD key) -- no host round trip per candidate."""
+        from .engine import select_payload
         import torch
         eng = self.engine
         L = self._list_size
@@ -217,9 +291,9 @@ class WatermarkDetector:
             raise NotImplementedError(
                 f"list_size={L}: the HIP decoder supports powers of two up to {eng.list_size_max}")
         B = len(ctrs)
-        y = self._dev(np.tile(np.asarray(frame, dtype=np.float64).reshape(1, -1), (B, 1)), np.float64)
-        bands = self._dev(np.array([self._band_id(choose_band(self._band_key, c)) for c in ctrs]), np.uint8)
-        pn = self._dev(self._pn_rows(ctrs), np.uint8)
+        y = frames[torch.tensor(rows, device=eng.device)].contiguous()
+        # PN rows and band indices of the candidate counters straight from the device schedule (es_schedule_batch)
+        pn, bands = eng.schedule(self.sec._prng.sub_key, self._band_key, ctrs=torch.tensor(ctrs, dtype=torch.int64))
         l0 = eng.llr(y, bands, pn, variant=0)
         l1 = eng.llr(y, bands, pn, variant=1)
         res = eng.scl(torch.cat((l0, -l0, l1, -l1), dim=0), list_size=L, skip_if_hard_ok=False)

@@ -120,3 +120,19 @@ def test_negative_cases_like_reference_suite(engine):
     assert det256._list_size == 256
     frame = WatermarkEmbedder(KEY)._make_frame_chips()
     assert det256._try_decode_frame(det256._bandpass(frame, (8000, 10000)), 0) in (True, False)
+
+
+@pytest.mark.gpu
+def test_verify_batch_equals_sequential_verify(engine):
+    """verify_batch(clips) == [verify(c) for c in clips]: results, try order (trace) and session-nonce evolution; clips of
+    several lengths (grouped launches), degenerate ones included."""
+    g3 = np.load(os.path.join(GOLD, "verify3s.npz")); g1 = np.load(os.path.join(GOLD, "verify_trace.npz"))
+    rng = np.random.default_rng(3)
+    clips = [g1["clip"], g3["clip"][:48000], rng.normal(0, 0.1, 12000).astype(np.float32), np.zeros(12000, np.float32),
+             np.zeros(10, np.float32), g1["clip"][::-1].copy(), g3["clip"][:48000] * 0.5]
+    a = WatermarkDetector(KEY, list_size=2, engine=engine); a._trace = []; a._hdr_trace = []
+    seq = [a.verify(c, 48_000) for c in clips]
+    b = WatermarkDetector(KEY, list_size=2, engine=engine); b._trace = []; b._hdr_trace = []
+    assert b.verify_batch(clips, 48_000) == seq
+    assert a._trace == b._trace and a._hdr_trace == b._hdr_trace and a.session_nonce == b.session_nonce
+    assert len(a._trace) > 20
