@@ -307,8 +307,8 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     ES_REQUIRE_READY(ctx);
     if (B < 0) return fail(ctx, ES_EINVAL, "es_scl_batch: negative batch");
     if (dtype != ES_DTYPE_F32 && dtype != ES_DTYPE_F64) return fail(ctx, ES_EINVAL, "es_scl_batch: dtype must be f32 or f64");
-    if (list_size < 1 || list_size > ctx->list_size_max || (list_size & (list_size - 1)))
-        return fail(ctx, ES_EINVAL, "es_scl_batch: list_size must be a power of two in [1, list_size_max]");
+    if (list_size < 1 || list_size > ctx->list_size_max)
+        return fail(ctx, ES_EINVAL, "es_scl_batch: list_size must be in [1, list_size_max]");
     if (B == 0) return ES_OK;
     if (!llr_dev || !hard_info_dev || !hard_ok_dev || !cand_info_dev || !cand_metric_dev || !cand_ok_dev || !ncand_dev)
         return fail(ctx, ES_EINVAL, "es_scl_batch: null pointer");
@@ -316,13 +316,14 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     if (list_size > 32)
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
-    if (list_size <= 16) {
+    int lp = 1; while (lp < list_size) lp <<= 1;              // the kernels are built for powers of two; any size runs on the next one
+    if (lp <= 16) {
         // several frames per wave (es_scl_multi.hip) once the batch yields enough such waves (16/L frames each).  One
         // frame per wave wastes more lanes the shorter the list is, so the break-even moves down with L: measured
         // at L = 8 it is two waves per SIMD (B = 4 096), at L = 1 a quarter of a wave per SIMD.
-        const long long waves = (B * list_size + 15) / 16;
+        const long long waves = (B * lp + 15) / 16;
         // (L = 16 runs on that kernel too when forced, but measures no faster than one frame per wave: auto leaves it alone)
-        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && list_size <= 8 && waves >= (long long)ctx->num_cu * list_size);
+        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && lp <= 8 && waves >= (long long)ctx->num_cu * lp);
         if (multi)
             return es_launch_scl_multi(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                        cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);

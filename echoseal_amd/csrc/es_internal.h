@@ -40,7 +40,7 @@ struct es_ctx {
     uint8_t* d_hdr_pn = nullptr;      /* packed header PN (es_tx_frames_batch) */
     int*     d_nflag = nullptr;       /* records the fused sync kernel handed to the float64 kernels (per call) */
     bool pick_attr_set = false;       /* per-device kernel attributes already raised for this context's device */
-    bool wide_attr_set = false;
+    unsigned wide_attr_mask = 0;      /* bit per wide-list kernel instantiation (64 / 128 / 256) */
     /* tuning (es_set_option) */
     int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
 };
@@ -53,6 +53,9 @@ struct es_ctx {
             return ES_EHIP;                                                             \
         }                                                                               \
     } while (0)
+
+/* kernels exist for power-of-two list sizes; a context created for list_size_max serves every size up to the next one */
+static inline int es_list_cap(int lmax) { int c = 1; while (c < lmax) c <<= 1; return c; }
 
 /* launchers implemented in the kernel translation units */
 size_t es_scl_scratch_bytes(const es_ctx* ctx);

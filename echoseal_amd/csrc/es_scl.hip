@@ -130,8 +130,8 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
             wave_fence_lds();
             if (ok && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
                 if (lane == 0) a.ncand[f] = 0;
-                for (int k = lane; k < L * ES_INFO_BYTES; k += 64) a.cand_info[f * L * ES_INFO_BYTES + k] = 0;
-                if (lane < L) { a.cand_metric[f * L + lane] = 0.0; a.cand_ok[f * L + lane] = 0; }
+                for (int k = lane; k < a.lsz * ES_INFO_BYTES; k += 64) a.cand_info[f * a.lsz * ES_INFO_BYTES + k] = 0;
+                if (lane < a.lsz) { a.cand_metric[f * a.lsz + lane] = 0.0; a.cand_ok[f * a.lsz + lane] = 0; }
                 continue;
             }
         }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
                 if constexpr (P >= 32) rank += xor_lanes_b32<16>(rank, lane);
                 if constexpr (P >= 64) rank += xor_lanes_b32<32>(rank, lane);
                 ES_STAMP(t_s2);
-                const int keep = nc < L ? nc : L;
+                const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= L: lists of any size run on the next power of two's kernel
                 // new path r continues the candidate of rank r; `src` = lane holding that candidate
                 // (parent * P + bit).  Dead paths mirror rank 0.
                 // (an inverse permutation through per-rank ballots and a v_readlane rank loop were both
@@ -529,13 +529,13 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
                 if ((tt & 7) == 0) { W.outb[path][tt >> 3] = (uint8_t)acc; acc = 0; }
             }
             const int ok = crc8_bytes(W.outb[path], ES_INFO_BYTES) == W.outb[path][ES_INFO_BYTES];
-            a.cand_metric[f * L + rank] = metric;
-            a.cand_ok[f * L + rank] = (uint8_t)ok;
+            a.cand_metric[f * a.lsz + rank] = metric;
+            a.cand_ok[f * a.lsz + rank] = (uint8_t)ok;
         }
         wave_fence_lds();
         if (path < cnt) {
             for (int k = q; k < ES_INFO_BYTES; k += P)
-                a.cand_info[(f * L + rank) * ES_INFO_BYTES + k] = W.outb[path][k];
+                a.cand_info[(f * a.lsz + rank) * ES_INFO_BYTES + k] = W.outb[path][k];
         }
         if (lane == 0) a.ncand[f] = cnt;
         wave_fence_lds();
@@ -654,7 +654,7 @@ int launch_scl(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
 size_t es_scl_scratch_bytes(const es_ctx* ctx)
 {
     size_t need = 0, n;
-    const int lmax = ctx->list_size_max;   /* lists above 32 use es_scl_wide.hip */
+    const int lmax = es_list_cap(ctx->list_size_max);   /* lists above 32 use es_scl_wide.hip */
     if (lmax >= 1  && (n = scl_scratch_need<1>(ctx))  > need) need = n;
     if (lmax >= 2  && (n = scl_scratch_need<2>(ctx))  > need) need = n;
     if (lmax >= 4  && (n = scl_scratch_need<4>(ctx))  > need) need = n;
@@ -675,7 +675,9 @@ int es_launch_scl(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int
     a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
     a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
     a.skip_if_hard_ok = skip_if_hard_ok;
-    switch (L) {
+    a.lsz = L;
+    int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
+    switch (LP) {
         case 1:  return launch_scl<1>(ctx, a, B, st);
         case 2:  return launch_scl<2>(ctx, a, B, st);
         case 4:  return launch_scl<4>(ctx, a, B, st);

@@ -33,6 +33,7 @@ struct SclArgs {
     uint8_t* hard_info; uint8_t* hard_ok;
     uint8_t* cand_info; double* cand_metric; uint8_t* cand_ok; int32_t* ncand;
     int skip_if_hard_ok;
+    int lsz;                                  // the caller's list size (<= the kernel's template capacity L): paths kept per sort, row stride of the outputs
 };
 
 __device__ __forceinline__ uint64_t ptr_set(uint64_t p, int depth, int slot)

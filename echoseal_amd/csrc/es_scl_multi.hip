@@ -135,8 +135,8 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
             wave_fence_lds();
             if (ok && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
                 if (lane == 0) a.ncand[ff] = 0;
-                for (int k = lane; k < L * ES_INFO_BYTES; k += 64) a.cand_info[ff * L * ES_INFO_BYTES + k] = 0;
-                if (lane < L) { a.cand_metric[ff * L + lane] = 0.0; a.cand_ok[ff * L + lane] = 0; }
+                for (int k = lane; k < a.lsz * ES_INFO_BYTES; k += 64) a.cand_info[ff * a.lsz * ES_INFO_BYTES + k] = 0;
+                if (lane < a.lsz) { a.cand_metric[ff * a.lsz + lane] = 0.0; a.cand_ok[ff * a.lsz + lane] = 0; }
             } else active_mask |= 1u << fi;
         }
         if (active_mask == 0) continue;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
                     rank += ((k < nc) && ((mk < mc) || (mk == mc && k < cc_))) ? 1 : 0;
                 }
                 rank += xor_lanes_b32<2>(rank, lane);
-                const int keep = nc < L ? nc : L;
+                const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= L: lists of any size run on the next power of two's kernel
                 if (is_cand && rank < keep) W.sel[fp0 + rank] = (uint8_t)cl;
                 wave_fence_lds();
                 const int cc = W.sel[fp0 + (pl < keep ? pl : 0)];
@@ -494,14 +494,14 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
             }
             if (f_store) {
                 const int ok = crc8_bytes(W.outb[path], ES_INFO_BYTES) == W.outb[path][ES_INFO_BYTES];
-                a.cand_metric[f * L + rank] = metric;
-                a.cand_ok[f * L + rank] = (uint8_t)ok;
+                a.cand_metric[f * a.lsz + rank] = metric;
+                a.cand_ok[f * a.lsz + rank] = (uint8_t)ok;
             }
         }
         wave_fence_lds();
         if (pl < cnt && f_store) {
             for (int k = q; k < ES_INFO_BYTES; k += P)
-                a.cand_info[(f * L + rank) * ES_INFO_BYTES + k] = W.outb[path][k];
+                a.cand_info[(f * a.lsz + rank) * ES_INFO_BYTES + k] = W.outb[path][k];
         }
         if (q == 0 && pl == 0 && f_store) a.ncand[f] = cnt;
         wave_fence_lds();
@@ -544,7 +544,9 @@ int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int 
     a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
     a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
     a.skip_if_hard_ok = skip_if_hard_ok;
-    switch (L) {
+    a.lsz = L;
+    int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
+    switch (LP) {
         case 1: return launch_multi<1>(ctx, a, B, st);
         case 2: return launch_multi<2>(ctx, a, B, st);
         case 4: return launch_multi<4>(ctx, a, B, st);

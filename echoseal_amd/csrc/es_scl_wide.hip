@@ -31,6 +31,7 @@ struct WideArgs {
     uint8_t* hard_info; uint8_t* hard_ok;
     uint8_t* cand_info; double* cand_metric; uint8_t* cand_ok; int32_t* ncand;
     int skip_if_hard_ok;
+    int lsz;                                  // the caller's list size (<= L)
 };
 
 __device__ __forceinline__ uint8_t crc8_bytes_w(const uint8_t* b, int n)
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
         __syncthreads();
         if (W.flag && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
             if (p == 0) a.ncand[f] = 0;
-            for (int k = p; k < L * ES_INFO_BYTES; k += L) a.cand_info[f * L * ES_INFO_BYTES + k] = 0;
-            a.cand_metric[f * L + p] = 0.0; a.cand_ok[f * L + p] = 0;
+            for (int k = p; k < a.lsz * ES_INFO_BYTES; k += L) a.cand_info[f * a.lsz * ES_INFO_BYTES + k] = 0;
+            if (p < a.lsz) { a.cand_metric[f * a.lsz + p] = 0.0; a.cand_ok[f * a.lsz + p] = 0; }
             __syncthreads();
             continue;
         }
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
                     }
                 }
                 __syncthreads();
-                const int keep = nc < L ? nc : L;
+                const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= L: lists of any size run on the next power of two's kernel
                 const int myr = p < keep ? p : 0;
                 const int myc = W.sidx[myr];
                 const double mym = W.candm[myr];
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
             rank += ((mk < metric) || (mk == metric && k < p)) ? 1 : 0;
         }
         if (p < cnt) {
-            uint8_t* out = a.cand_info + (f * L + rank) * ES_INFO_BYTES;
+            uint8_t* out = a.cand_info + (f * a.lsz + rank) * ES_INFO_BYTES;
             int curp = p;
             uint32_t acc = 0, reg = 0, last = 0;
             // trace back from the last information step; bytes come out last-to-first, so the CRC
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
                 #pragma unroll
                 for (int b = 0; b < 8; ++b) reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
             }
-            a.cand_metric[f * L + rank] = metric;
-            a.cand_ok[f * L + rank] = (uint8_t)(reg == last);
+            a.cand_metric[f * a.lsz + rank] = metric;
+            a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == last);
         }
         if (p == 0) a.ncand[f] = cnt;
         __syncthreads();
@@ -337,11 +338,10 @@ template <int L>
 int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
 {
     const size_t lds = sizeof(WideLds<L>);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx->wide_attr_mask & (unsigned)L)) {      // per context (= per device): the attribute belongs to the device's copy of the kernel
         ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_scl_wide_kernel<L>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        ctx->wide_attr_mask |= (unsigned)L;
     }
     long long blocks = B;
     const long long cap = ctx->wide_slots;
@@ -359,7 +359,7 @@ size_t es_scl_wide_scratch_bytes(const es_ctx* ctx, int* slots_out)
     if (ctx->list_size_max <= 32) { *slots_out = 0; return 0; }
     const int slots = ctx->num_cu * 2;
     *slots_out = slots;
-    const size_t Lm = (size_t)ctx->list_size_max;
+    const size_t Lm = (size_t)(es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max));
     return (size_t)slots * (N * Lm * sizeof(double) + KINFO * Lm * sizeof(uint16_t));
 }
 
@@ -373,11 +373,12 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
     a.frozen = ctx->frozen; a.data_pos = ctx->d_data_pos; a.exp_tab = ctx->d_exp_tab;
     a.alpha = reinterpret_cast<double*>(ctx->d_wide_scratch);
     a.tb = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(ctx->d_wide_scratch) +
-                                       (size_t)ctx->wide_slots * N * (size_t)ctx->list_size_max * sizeof(double));
+                                       (size_t)ctx->wide_slots * N * (size_t)(es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max)) * sizeof(double));
     a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
     a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
     a.skip_if_hard_ok = skip_if_hard_ok;
-    switch (L) {
+    a.lsz = L;
+    switch (L <= 64 ? 64 : (L <= 128 ? 128 : 256)) {
         case 64:  return launch_wide<64>(ctx, a, B, st);
         case 128: return launch_wide<128>(ctx, a, B, st);
         case 256: return launch_wide<256>(ctx, a, B, st);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * BPF_WAVES) void es_bpf_kernel(const void* __re
             const long long rr = rec0 + r;
             float v = 0.0f;
             if (rr < B && t0 + col < T) {
-                if (I16) v = (float)((const int16_t*)frames)[rr * T + t0 + col] / 32767.0f;
+                if (I16) v = (float)((const int16_t*)frames)[rr * T + t0 + col] * (1.0f / 32768.0f);   // PCM16 as soundfile.read hands it to the reference (rx_app.py:26): exact in float32
                 else v = ((const float*)frames)[rr * T + t0 + col];
             }
             s_x[wv][r][col] = v;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void es_bpf_quad_kernel(const void* 
             const long long rr = rec0 + 2 * i + half;
             float v = 0.0f;
             if (rr < B && t0 + col < T) {
-                if (I16) v = (float)((const int16_t*)frames)[rr * T + t0 + col] / 32767.0f;
+                if (I16) v = (float)((const int16_t*)frames)[rr * T + t0 + col] * (1.0f / 32768.0f);   // PCM16 as soundfile.read hands it to the reference (rx_app.py:26): exact in float32
                 else v = ((const float*)frames)[rr * T + t0 + col];
             }
             pre[i] = v;

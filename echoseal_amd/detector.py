@@ -287,9 +287,8 @@ class WatermarkDetector:
         import torch
         eng = self.engine
         L = self._list_size
-        if L > eng.list_size_max or (L & (L - 1)):
-            raise NotImplementedError(
-                f"list_size={L}: the HIP decoder supports powers of two up to {eng.list_size_max}")
+        if L > eng.list_size_max:
+            raise NotImplementedError(f"list_size={L}: the HIP decoder supports list sizes up to {eng.list_size_max}")
         B = len(ctrs)
         y = frames[torch.tensor(rows, device=eng.device)].contiguous()
         # PN rows and band indices of the candidate counters straight from the device schedule (es_schedule_batch)

@@ -109,9 +109,8 @@ class PolarCode:
         import torch
         from .engine import select_payload
         eng = default_engine()
-        if self.list_size > eng.list_size_max or (self.list_size & (self.list_size - 1)):
-            raise NotImplementedError(
-                f"list_size={self.list_size}: the HIP decoder supports powers of two up to {eng.list_size_max}")
+        if self.list_size > eng.list_size_max:
+            raise NotImplementedError(f"list_size={self.list_size}: the HIP decoder supports list sizes up to {eng.list_size_max}")
         host = np.ascontiguousarray(llr, dtype=np.float32 if llr.dtype == np.float32 else np.float64)
         dev = torch.from_numpy(host).to(eng.device).reshape(1, self.N)
         res = eng.scl(dev, list_size=self.list_size, skip_if_hard_ok=(validator is None))

@@ -154,7 +154,8 @@ int es_header_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const in
 /* Polar(1024,448)+CRC-8 decode: hard-decision shortcut and successive-cancellation list.
  *   replaces PolarCode.decode (rtwm/fastpolar.py:254-359) up to validator selection
  *   llr_dev         [B][1024] ES_DTYPE_F32 or ES_DTYPE_F64
- *   list_size       a power of two, 1..256 (<= the context's list_size_max)
+ *   list_size       1..256 (<= the context's list_size_max); any size, as in the reference: a size that is not a power of
+ *                   two runs on the next power of two's kernel with the surplus paths switched off
  *   skip_if_hard_ok non-zero: records whose hard decision passes CRC skip the list loop
  *                   (the reference's behaviour when validator is None, fastpolar.py:268-276)
  *   hard_info_dev   [B][55], hard_ok_dev [B]

@@ -16,6 +16,7 @@ and never travels).  Only inputs and outputs are stored under tests/golden/ -- n
     polar_bulk.npz      1 024 LLR vectors (AWGN sigma 0.3-1.1, detector-produced = the c3 LLRs, tie-heavy, garbage, wide
                         range float64) through PolarCode.decode(list_size=8): (info, ok), final list (bits, metrics, CRC
                         flags) in both NumPy run-time modes (see gen_golden.py: `default` / `glibc`).
+    polar_odd_*.npz     PolarCode.decode with list sizes that are not powers of two (3, 5, 6, 12, 24, 100), both NumPy modes.
     polar_validator.npz PolarCode.decode WITH a validator (rtwm/fastpolar.py:268-276, 335-359): reject-all, accept the
                         k-th call, raising validator, accept-one-payload, and the detector's own AEAD closure
                         (rtwm/detector.py:168-176) with the right and a wrong counter; records every payload the
@@ -506,12 +507,33 @@ def gen_validator(workers=8):
     np.savez_compressed(os.path.join(GOLD, "polar_validator.npz"), **out)
 
 
+# ----------------------------------------------------------------------------------------------- list sizes that are not powers of two
+ODD_LISTS = (3, 5, 6, 12, 24, 100)
+
+
+def gen_odd(mode):
+    """PolarCode.decode with list sizes that are not powers of two (the reference takes any list_size >= 1)."""
+    import numpy as np
+    from oracle.refshim.shim import load_reference
+    load_reference()
+    import rtwm.fastpolar as fp
+    from oracle.refshim import gen_golden as G
+    base = np.load(os.path.join(GOLD, "polar_default.npz"))
+    bulk = np.load(os.path.join(GOLD, "polar_bulk_glibc.npz"))
+    cases = {"garbage_rng7": base["garbage_rng7/llr"], "det_clean_ctr0": base["det_clean_ctr0/llr"], "awgn070": base["awgn070/llr"],
+             "c3_llr_17": bulk["llr"][17], "tie_heavy_600": bulk["llr"][600]}
+    G.LISTS = ODD_LISTS
+    out = G.run_polar(np, fp, cases)
+    out["meta/mode"] = np.array(mode)
+    np.savez_compressed(os.path.join(GOLD, f"polar_odd_{mode}.npz"), **out)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     if what == "all":
         subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r2", "c3"], cwd=ROOT, env=env)
-        for w in ("multi", "verify", "validator", "bulk"):
+        for w in ("multi", "verify", "validator", "bulk", "odd"):
             subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r2", w], cwd=ROOT, env=env)
     elif what == "c3":
         gen_c3()
@@ -525,6 +547,12 @@ def main():
         subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r2", "bulk_default"], cwd=ROOT, env=env)
         env["NPY_DISABLE_CPU_FEATURES"] = AVX512_OFF
         subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r2", "bulk_glibc"], cwd=ROOT, env=env)
+    elif what == "odd":
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r2", "odd_default"], cwd=ROOT, env=env)
+        env["NPY_DISABLE_CPU_FEATURES"] = AVX512_OFF
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r2", "odd_glibc"], cwd=ROOT, env=env)
+    elif what in ("odd_default", "odd_glibc"):
+        gen_odd(what.split("_")[1])
     elif what in ("bulk_default", "bulk_glibc"):
         gen_bulk(what.split("_")[1], workers=int(os.environ.get("GOLD_WORKERS", "6")))
     else:

@@ -232,3 +232,24 @@ def test_oracle_select_validated_matches_reference(oracle):
         assert ok == int(bool(g[f"{t}/ok"])) and payload == g[f"{t}/info"].tobytes(), i
         done += 1
     assert done >= 90
+
+
+@pytest.mark.parametrize("mode", ["glibc", "default"])
+def test_list_sizes_that_are_not_powers_of_two(oracle, mode):
+    """The reference takes any list_size >= 1 (rtwm/fastpolar.py:215); fixtures for 3, 5, 6, 12, 24, 100."""
+    g = _g(f"polar_odd_{mode}.npz")
+    names = sorted({k.split("/")[0] for k in g.files if k.endswith("/llr")})
+    checked = 0
+    for name in names:
+        llr = g[f"{name}/llr"]
+        for L in (3, 5, 6, 12, 24, 100):
+            info, ok, took = oracle.polar_decode(llr, L)
+            assert ok == bool(g[f"{name}/L{L}/ok"]) and np.array_equal(np.packbits(info), g[f"{name}/L{L}/info"]), (name, L)
+            key = f"{name}/L{L}/cand_metric"
+            if key in g.files:
+                n, ci, cm, cc = oracle.scl_list(llr, L)
+                assert n == L and np.array_equal(np.packbits(ci, axis=1), g[f"{name}/L{L}/cand_info"]), (name, L)
+                assert np.array_equal(cm, g[key]) if mode == "glibc" else np.allclose(cm, g[key], rtol=1e-12, atol=0)
+                assert np.array_equal(cc, g[f"{name}/L{L}/cand_crc"])
+                checked += 1
+    assert checked >= 20

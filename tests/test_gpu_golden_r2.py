@@ -153,3 +153,45 @@ def test_verify_3s_clip_follows_reference(engine):
     assert hdr.shape == g["hdr"].shape
     assert np.array_equal(hdr[:, :2], g["hdr"][:, :2])
     assert np.max(np.abs(hdr[:, 2] - g["hdr"][:, 2]) / np.maximum(1.0, np.abs(g["hdr"][:, 2]))) <= 1e-4
+
+
+def test_list_sizes_that_are_not_powers_of_two(engine, oracle):
+    """Any list size 1..256 (the reference takes any): the next power of two's kernel with the surplus paths switched
+    off.  Against the reference fixtures (3, 5, 6, 12, 24, 100) and, for more sizes and frames, against the oracle."""
+    g = _g("polar_odd_glibc.npz")
+    names = sorted({k.split("/")[0] for k in g.files if k.endswith("/llr")})
+    big = RxEngineBig.get(engine)
+    llr = np.stack([np.asarray(g[f"{n}/llr"], np.float64) for n in names])
+    for L in (3, 5, 6, 12, 24, 100):
+        res = big.scl(torch.from_numpy(llr).to(big.device), list_size=L, skip_if_hard_ok=False)
+        for r, n in enumerate(names):
+            if f"{n}/L{L}/cand_metric" in g.files:
+                assert np.array_equal(res.cand_info[r].cpu().numpy(), g[f"{n}/L{L}/cand_info"]), (n, L)
+                assert np.array_equal(res.cand_metric[r].cpu().numpy().view(np.uint64), g[f"{n}/L{L}/cand_metric"].view(np.uint64)), (n, L)
+                assert np.array_equal(res.cand_ok[r].cpu().numpy(), g[f"{n}/L{L}/cand_crc"])
+    rng = np.random.default_rng(77)
+    x = np.clip(rng.normal(0, 3, (40, 1024)), -12, 12).astype(np.float32)
+    x[0] = 0.0; x[0, 0] = 1e-3
+    for L in (3, 7, 9, 15, 17, 31, 33, 48, 65, 127, 129, 200, 255):
+        for multi in ((0, 1) if L <= 16 else (0,)):
+            big.set_option("scl_multi", multi)
+            res = big.scl(torch.from_numpy(x).to(big.device), list_size=L, skip_if_hard_ok=False)
+            big.set_option("scl_multi", -1)
+            assert res.cand_metric.shape == (40, L)
+            for i in range(0, 40, 3 if L < 64 else 13):
+                nn, ci, cm, cc = oracle.scl_list(x[i].astype(np.float64), L)
+                assert int(res.ncand[i]) == L
+                assert np.array_equal(np.packbits(ci, axis=1), res.cand_info[i].cpu().numpy()), (L, multi, i)
+                assert np.array_equal(cm, res.cand_metric[i].cpu().numpy()) and np.array_equal(cc, res.cand_ok[i].cpu().numpy())
+
+
+class RxEngineBig:
+    """An engine created for list sizes up to 256 (shared by the tests of this module)."""
+    _eng = None
+
+    @classmethod
+    def get(cls, engine):
+        if cls._eng is None:
+            from echoseal_amd.engine import RxEngine
+            cls._eng = RxEngine(engine.device.index, list_size_max=256)
+        return cls._eng

@@ -169,9 +169,10 @@ def test_edge_records(engine, oracle):
     band = np.array([3, 0, 2], np.uint8)
     f, b = _dev(engine, xi, band)
     yi = engine.bpf(f, b).cpu().numpy()
+    xf = xi.astype(np.float32) / np.float32(32768)         # what soundfile.read returns for PCM16 (rx_app.py:26); exact in float32
+    assert np.array_equal(yi, engine.bpf(torch.from_numpy(xf).to(engine.device), b).cpu().numpy())     # int16 ingest == float32 path
     for i in range(3):
-        xf = (xi[i].astype(np.float32) / np.float32(32767))
-        assert np.array_equal(yi[i], oracle.lfilter(ba[band[i], :9], ba[band[i], 9:], xf))
+        assert np.array_equal(yi[i], oracle.lfilter(ba[band[i], :9], ba[band[i], 9:], xf[i]))
     # frames starting inside a longer window, including one that runs off the end
     frames, bnd, pn = _workload(4)
     win = np.zeros((4, 2048), np.float32); starts = np.array([0, 100, 833, 1500], np.int32)
@@ -190,9 +191,9 @@ def test_edge_records(engine, oracle):
     assert engine.scl(e, list_size=8).ncand.numel() == 0
     from echoseal_amd._native import NativeError
     with pytest.raises(NativeError):
-        engine.scl(torch.zeros((1, 1024), device=engine.device), list_size=3)
+        engine.scl(torch.zeros((1, 1024), device=engine.device), list_size=0)
     with pytest.raises(NativeError):
-        engine.scl(torch.zeros((1, 1024), device=engine.device), list_size=64)
+        engine.scl(torch.zeros((1, 1024), device=engine.device), list_size=64)       # above this context's list_size_max
 
 
 def test_polar_encode_kernel(engine, oracle):

@@ -100,3 +100,27 @@ def test_hot_path_fails_loudly_without_gpu():
     from echoseal_amd._native import NativeError
     with pytest.raises(NativeError):
         decode(np.ones(1024))
+
+
+def test_declared_limits_raise_not_implemented():
+    """The documented limits of the drop-in are an explicit error contract, raised BEFORE any GPU work:
+    the HIP decoder is built for Polar(1024,448)+CRC-8 (the only code the reference instantiates, rtwm/polar_fast.py:18-24)
+    and the detector for fs_target = 48 000 (rtwm/detector.py:27).  Constructing such objects works, as in the reference."""
+    from rtwm.fastpolar import PolarCode
+    from rtwm.detector import WatermarkDetector
+    with pytest.raises(ValueError):                                            # as in the reference: the reliability table has 1024 entries
+        PolarCode(512, 224)
+    for n, k, crc in ((1024, 512, 8), (1024, 300, 8), (1024, 64, 8)):      # (the reference's encode only works with crc_size 8, too)
+        pc = PolarCode(n, k, crc_size=crc)
+        code = pc.encode(np.zeros(k - crc, np.uint8))                          # the TX side is generic host code
+        assert code.shape == (n,)
+        with pytest.raises(NotImplementedError, match="Polar\\(1024,448\\)"):
+            pc.decode(np.ones(n))
+    det = WatermarkDetector(bytes(32), fs_target=44_100)
+    assert det.fs_target == 44_100
+    import torch
+    if torch.cuda.is_available():
+        with pytest.raises(NotImplementedError, match="fs_target"):
+            det.verify(np.zeros(5000, np.float32), 44_100)
+    # list sizes: any value >= 1 is accepted, as in the reference; the HIP kernels serve up to 256
+    assert PolarCode(1024, 448, list_size=3).list_size == 3 and PolarCode(1024, 448, list_size=1000).list_size == 1000
