@@ -427,20 +427,21 @@ def run_rank(a) -> None:
         if roof_c3 is not None:
             out["roofline"] = roof_c3
             out["roofline_fused"] = roof_fused
-            out["roofline_c2"] = c2_roof
         else:
-            out["roofline"] = c2_roof
-        scl_pmc = (_profile_json("r02_scl_pmc.json") or _profile_json("r01_scl_pmc.json") or {})
-        key = next((k for k in scl_pmc if k.startswith("es_scl_kernel<8>")), None)
+            out["roofline"] = c2_roof                     # no c3 leg in this run: the fused sync launch of the headline steps
+        scl_pmc = _profile_json("r02_scl_pmc.json") or {}
+        kname = "es_scl_multi_kernel<8>" if (a.lanes and a.scl_multi == 1) else "es_scl_kernel<8>"
+        key = next((k for k in scl_pmc if k.startswith(kname)), None)
         if key and L == 8:
             vi = scl_pmc[key]["per_frame"]["valu_instructions"]
             rate = vi * (total / world) * a.steps / dt / 1e9                    # per GPU
-            out["roofline_scl"] = {"kernel": "es_scl_kernel<8> (the dominant kernel by time: >80 % of a step)", "bound": "fp64 vector issue",
+            out["roofline_scl"] = {"kernel": kname + " (the dominant kernel by time: ~85 % of a step's GPU work)", "bound": "fp64 vector issue",
                                    "achieved": rate, "peak": FP64_ISSUE_PEAK_GWIPS, "unit": "G wave-instructions/s", "frac": rate / FP64_ISSUE_PEAK_GWIPS,
                                    "valu_wave_instructions_per_frame": vi,
-                                   "how": "vector wave-instructions per frame (SQ_INSTS_VALU / frames, committed PMC pass in profiles/) x frames/s per GPU of "
-                                          "the timed headline steps; peak = 78.6 TFLOP/s FP64 vector = one wave64 instruction per 4 cycles on each of "
-                                          "1 024 SIMDs at 2.4 GHz; the kernel is not HBM- or MFMA-bound (4 096 B in, <= 520 B out per frame)"}
+                                   "how": "vector wave-instructions per frame (SQ_INSTS_VALU / frames, PMC pass committed as profiles/r02_scl_pmc.json, same kernel) "
+                                          "x frames/s per GPU of the timed headline steps; peak = 78.6 TFLOP/s FP64 vector = one wave64 instruction per 4 cycles on "
+                                          "each of 1 024 SIMDs at 2.4 GHz (PMC: 4.15 vector-unit cycles per instruction in this kernel); the kernel is not HBM- or "
+                                          "MFMA-bound (4 096 B in, <= 520 B out per frame)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_h, band_d.cpu().numpy(), pn_d.cpu().numpy(), L)
         print(json.dumps(out), flush=True)

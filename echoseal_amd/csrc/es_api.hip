@@ -194,21 +194,9 @@ int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, 
     if (!y32_dev || !y_dev || !band_dev || !thr_dev || !peaks_dev || !npeaks_dev || !flags_dev)
         return fail(ctx, ES_EINVAL, "es_sync_fused_batch: null pointer");
     DeviceGuard g(ctx->device);
-    const int n_lags = T - (ES_PRE_L - 1);
-    const size_t need = (size_t)B * n_lags * sizeof(double);       // float64 workspace of the redo pass (es_reserve sizes it ahead of time)
-    if (need > ctx->ws_corr_bytes) {
-        int rc0 = es_reserve(ctx, B, T);
-        if (rc0) return rc0;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    ES_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_nflag, 0, sizeof(int), st));
-    int rc = es_launch_sync_fused(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, ctx->d_nflag, st);
-    if (rc) return rc;
-    /* records the screen could not settle (flags != 0; counted on the device): redone by the float64 kernels -- two
-       launches of a few blocks that leave at once when the counter reads zero */
-    rc = es_launch_xcorr_flagged(ctx, y_dev, B, T, band_dev, ctx->d_ws_corr, flags_dev, ctx->d_nflag, st);
-    if (rc) return rc;
-    return es_launch_pick_flagged(ctx, ctx->d_ws_corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, flags_dev, ctx->d_nflag, st);
+    /* one launch: records the screen cannot settle are settled by the same wave from float64 re-evaluations (flags_dev
+       then carries the reason code, for information) */
+    return es_launch_sync_fused(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, nullptr, (hipStream_t)stream);
 }
 
 int es_reserve(es_ctx* ctx, int64_t B_max, int T_max)

@@ -50,7 +50,7 @@ constexpr double DELTA = 3e-5;
 // stays in LDS, and sync_pick_row() (defined after the picker's helpers) settles threshold and peaks from it -- HBM
 // sees 4 bytes per sample in and <= 150 bytes per record out ("4 860 + <= 64 B" per frame).
 constexpr int XF_WAVES = 2;                         // waves per block of the fused kernel (a block = 2 records in flight)
-constexpr int XF_MIN_WAVES = 2;                     // LDS (16-19 KB per wave) admits two waves per SIMD anyway
+constexpr int XF_MIN_WAVES = 3;                     // <= 168 VGPRs: a fused-sync wave fits the slot one list-decoder wave (168) leaves behind
 struct FusedArgs {
     const double* y64;                              // [B][T] float64 band-passed records (exact re-evaluations)
     double* thr; int32_t* peaks; int32_t* npeaks; uint8_t* flags;
@@ -395,6 +395,141 @@ __host__ __device__ __forceinline__ size_t xf_lds_per_wave(int ns2, int n_lags)
     return (size_t)((ns2 + 3) & ~3) * 4 + (((size_t)n_lags * 4 + 15) & ~(size_t)15) + sizeof(PwFixed);
 }
 
+// ------------------------------------------------------------------------------------ fused sync: the rare exact row
+// A record the screen cannot settle (hundreds of exactly equal correlations: digital silence, constants, exact repeats;
+// or a screen that overflowed float32) is settled HERE, by the same wave, entirely from float64 re-evaluations -- no
+// workspace and no second launch: every pass recomputes corr64_at(i) (bit-identical to es_xcorr_kernel) for the lags it
+// looks at.  Same rules and tie-breaks as es_pick_kernel: exact order statistics by 8-bit radix select on the monotone
+// 64-bit image of the doubles, NMS window +-607, fallback = five largest, equal values -> higher index first.  Slow
+// (16+ passes of ~200 float64 operations per lag) and meant to be: such records are degenerate.
+__device__ __forceinline__ uint64_t f64_key(double x)
+{
+    uint64_t b; __builtin_memcpy(&b, &x, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double key_f64(uint64_t k)
+{
+    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    double x; __builtin_memcpy(&x, &b, 8); return x;
+}
+
+template <typename F>
+__device__ double pw_select64(PwFixed& S, int n, int k, int lane, F val)
+{
+    uint64_t prefix = 0;
+    int kk = k;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        #pragma unroll
+        for (int b = 0; b < 4 * PW_HCOPIES; ++b) (&S.hist[0][0])[lane + 64 * b] = 0;
+        wave_fence_lds();
+        const uint64_t himask = (shift == 56) ? 0ULL : (~0ULL << (shift + 8));
+        uint32_t* const myh = S.hist[lane & (PW_HCOPIES - 1)];
+        for (int i = lane; i < n; i += 64) {
+            const uint64_t kx = f64_key(val(i));
+            if ((kx & himask) == prefix) atomicAdd(&myh[(uint32_t)(kx >> shift) & 255u], 1u);
+        }
+        wave_fence_lds();
+        uint32_t h[4];
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t t = 0;
+            #pragma unroll
+            for (int cpy = 0; cpy < PW_HCOPIES; ++cpy) t += S.hist[cpy][4 * lane + b];
+            h[b] = t;
+        }
+        const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
+        uint32_t incl = s4;
+        #pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        const uint32_t excl = incl - s4;
+        const bool hit = ((int)excl <= kk) && (kk < (int)incl);
+        int bin = 0, nk = 0;
+        if (hit) {
+            uint32_t c = excl;
+            #pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (kk >= (int)c && kk < (int)(c + h[b])) { bin = 4 * lane + b; nk = kk - (int)c; }
+                c += h[b];
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        const int src = __ffsll((long long)m) - 1;
+        bin = __shfl(bin, src); kk = __shfl(nk, src);
+        prefix |= (uint64_t)(uint32_t)bin << shift;
+        wave_fence_lds();
+    }
+    return key_f64(prefix);
+}
+
+__device__ __noinline__ void sync_exact_row(PwFixed& S, int n, const double* yr, const double* tpl, long long rec, int lane,
+                                            const FusedArgs& fo)
+{
+    const int min_distance = ES_FRAME_LEN / 2;
+    auto ex = [&](int i) { return corr64_at(yr, i, tpl); };
+    double med;
+    if (n & 1) med = pw_select64(S, n, n / 2, lane, ex);
+    else { const double lo = pw_select64(S, n, n / 2 - 1, lane, ex), hi = pw_select64(S, n, n / 2, lane, ex); med = (lo + hi) / 2.0; }
+    auto dev = [&](int i) { return __builtin_fabs(corr64_at(yr, i, tpl) - med); };
+    double mad;
+    if (n & 1) mad = pw_select64(S, n, n / 2, lane, dev);
+    else { const double lo = pw_select64(S, n, n / 2 - 1, lane, dev), hi = pw_select64(S, n, n / 2, lane, dev); mad = (lo + hi) / 2.0; }
+    mad = mad + 1e-12;
+    double thr = med + 4.5 * 1.4826 * mad;
+    if (0.95 < thr) thr = 0.95;
+
+    int total = 0;
+    for (int base = 0; base < n; base += 64) {                          // ascending lags; a candidate is checked by the whole wave
+        const int i = base + lane;
+        const double cv_mine = (i < n) ? ex(i) : 0.0;
+        unsigned long long m = __ballot((i < n) && !(cv_mine < thr));
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int ci = base + bit;
+            const double cv = __shfl(cv_mine, bit);
+            int lo = ci - min_distance; if (lo < 0) lo = 0;
+            int hi = ci + min_distance + 1; if (hi > n) hi = n;
+            bool bigger = false;
+            for (int j0 = lo; j0 < hi && !bigger; j0 += 64) {
+                const int j = j0 + lane;
+                if (__ballot((j < hi) && ex(j) > cv)) bigger = true;
+            }
+            if (bigger) continue;
+            if (lane == 0 && total < ES_MAX_PEAKS) fo.peaks[rec * ES_MAX_PEAKS + total] = ci;
+            ++total;
+        }
+    }
+    if (total == 0) {
+        const int kmax = n < 5 ? n : 5;                                 // five largest, descending; equal values -> higher index first
+        int taken[5] = {-1, -1, -1, -1, -1};
+        for (int r = 0; r < kmax; ++r) {
+            double bv = 0.0; int bi = -1;
+            for (int i = lane; i < n; i += 64) {
+                bool used = false;
+                #pragma unroll
+                for (int qd = 0; qd < 5; ++qd) used |= (qd < r) && (taken[qd] == i);
+                if (used) continue;
+                const double v = ex(i);
+                if (bi < 0 || v > bv || (v == bv && i > bi)) { bv = v; bi = i; }
+            }
+            #pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+            }
+            #pragma unroll
+            for (int qd = 0; qd < 5; ++qd) if (qd == r) taken[qd] = bi;
+            if (lane == 0) fo.peaks[rec * ES_MAX_PEAKS + r] = bi;
+        }
+        if (lane == 0) fo.npeaks[rec] = kmax | (1 << 30);
+        total = kmax;
+    } else if (lane == 0) {
+        fo.npeaks[rec] = total;
+    }
+    if (lane >= total && lane < ES_MAX_PEAKS) fo.peaks[rec * ES_MAX_PEAKS + lane] = -1;
+    if (lane == 0) fo.thr[rec] = thr;
+}
+
 // ------------------------------------------------------------------------------------ fused sync: threshold + peaks of one row
 // One wave, the float32 screen row c[0..n) in LDS.  Same decisions as es_pick_exact_wave_kernel (hence as the float64
 // path), reached with far fewer passes over the row in the common case:
@@ -416,7 +551,12 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
                               const FusedArgs& fo)
 {
     const int min_distance = ES_FRAME_LEN / 2;
-    auto flag_out = [&](int code) { if (lane == 0) { fo.flags[rec] = (uint8_t)code; if (fo.nflag) atomicAdd(fo.nflag, 1); } };
+    // a record the screen cannot settle: reason code to flags (informational), then the exact row by this same wave
+    auto flag_out = [&](int code) {
+        if (lane == 0) { fo.flags[rec] = (uint8_t)code; if (fo.nflag) atomicAdd(fo.nflag, 1); }
+        wave_fence_lds();
+        sync_exact_row(S, n, yr, tpl, rec, lane, fo);
+    };
     auto exact_corr = [&](int i) { return corr64_at(yr, i, tpl); };
     const int k_hi = n / 2, k_lo = (n & 1) ? n / 2 : n / 2 - 1;
     constexpr double BINW = 1.0 / 128.0;

@@ -108,16 +108,17 @@ int es_pick_exact_batch(es_ctx* ctx, const float* corr32_dev, const double* y_de
  * correlation row of a record stays in LDS, threshold (median / MAD or the proof that it saturates at 0.95) and peaks are
  * settled from it with float64 re-evaluation of every value near a decision, and only thr / peaks / npeaks / flags reach
  * HBM: 4 T bytes of samples in (+ the few float64 samples the re-evaluations read), <= 150 bytes out per record.
- * thr / peaks / npeaks bit-identical to es_xcorr_batch + es_pick_batch.  Records the screen cannot settle (flags_dev != 0:
- * non-finite or constant data) are counted on the device and redone by the float64 kernels inside the call; with none
- * flagged those two launches leave at once.  T - 62 <= 4096.
+ * thr / peaks / npeaks bit-identical to es_xcorr_batch + es_pick_batch.  Records the screen cannot settle (digital silence,
+ * constants, exact repeats, a float32 overflow) are settled by the same wave from float64 re-evaluations alone -- slowly, with
+ * no workspace and no second launch; flags_dev [B] then holds the reason code 1..5 (0 = settled from the screen), for
+ * information.  T - 62 <= 4096.
  *   replaces rtwm/detector.py:76-99                                                                                  */
 int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, int64_t B, int T,
                         const uint8_t* band_dev, double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev,
                         uint8_t* flags_dev, void* stream);
 
 /* Size the context's float64 correlation workspace (used by es_sync_batch without corr_dev, and by the redo pass of
- * es_pick_exact_batch / es_sync_fused_batch) for batches of up to B_max records of T_max samples.  Allocation synchronises
+ * es_pick_exact_batch) for batches of up to B_max records of T_max samples.  Allocation synchronises
  * the device: call this once, outside any stream capture; afterwards those entry points only enqueue.  Without it they
  * grow the workspace themselves the first time a larger batch arrives (same effect as calling es_reserve there).
  * One stream at a time per context: the workspace and the list decoder's scratch slab are shared by every call on it.   */

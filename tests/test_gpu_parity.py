@@ -900,3 +900,26 @@ def test_c4_full_2pow20_properties(engine):
     from echoseal_amd.utils import band_index
     for c in (0, 1, 65535, 65536, 999_999, n - 1):
         assert int(band[c]) == band_index(KEY, c)
+
+
+def test_c5_surrogate_list_sweep_vs_oracle(engine, oracle):
+    """BASELINE config 5 needs an MP3 codec; the image has none (MP3 itself: skipped).  The documented SURROGATE channel
+    (echoseal_amd.workloads.lossy_channel: 16 kHz low-pass + level-shaped noise -- NOT MP3) takes its place: list size swept
+    over 1 / 4 / 8 / 16, HIP == oracle on sync offsets, LLRs and (payload, ok) for every frame and list size."""
+    from echoseal_amd import workloads as WL
+    frames, band, pn, payloads = WL.c2_frames(range(96))
+    lossy = WL.lossy_channel(frames)
+    assert lossy.shape == frames.shape and np.isfinite(lossy).all() and not np.array_equal(lossy, frames)
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    f, b, p = _dev(engine, lossy, band, pn)
+    ref = [oracle.decode_frame(lossy[i], ba[band[i]], tpl[band[i]], taps[band[i], :ntaps[band[i]]], np.unpackbits(pn[i])[:1215], L=1)
+           for i in range(96)]
+    for L in (1, 4, 8, 16):
+        sy, llr, scl = engine.decode_batch(f, b, p, list_size=L)
+        payload, ok, which = engine.select(scl)
+        payload = payload.cpu().numpy(); ok = ok.cpu().numpy(); llr_h = llr.cpu().numpy()
+        for i in range(96):
+            k = int(sy.npeaks[i]) & 0xFFFF
+            assert list(sy.peaks[i, :k].cpu().numpy()) == list(ref[i]["peaks"][:k]) and np.array_equal(llr_h[i], ref[i]["llr"])
+            info, okr, _ = oracle.polar_decode(ref[i]["llr"].astype(np.float64), L)
+            assert np.packbits(info).tobytes() == payload[i].tobytes() and bool(okr) == (ok[i] == 1), (L, i)
