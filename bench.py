@@ -16,8 +16,10 @@ it once over RCCL before the timed region; the data path has no collective.
 
 Further driver-timed legs in the same JSON line (`legs`), each bracketed by barrier + synchronize like the headline:
   c3   BASELINE config 3 on one GPU: 65 536 windows of 2 048 samples (frame resampled +-5 %, random offset, AWGN at
-       -15 dB), end to end: band-pass -> float32 correlation screen -> exact peak picking -> _llr at the DETECTED peak ->
-       SCL-8 -> selection.  `roofline` is the correlation kernel INSIDE this leg (HIP events on its launch stream).
+       -15 dB), end to end: band-pass -> fused sync (float32 correlation row in LDS + exact threshold / peaks, one kernel) ->
+       _llr at the DETECTED peak -> SCL-8 -> selection.
+  c3_unfused  the same pass with the correlation row going through HBM (es_xcorr32_batch -> es_pick_exact_batch): identical
+       results; `roofline` is the stand-alone correlation kernel INSIDE this leg (HIP events on its launch stream).
   c4   BASELINE config 4, strong scaling: 2^20 frames in total, ctr 0 .. 2^20-1, sharded contiguously over the N
        ranks; rank 0 derives the whole key/PN schedule (153 B per counter = 160 MB) and broadcasts it (RCCL); every
        rank streams its shard through the path in 131 072-frame chunks.  A checksum over (frame index, payload, ok) is
@@ -26,10 +28,9 @@ Further driver-timed legs in the same JSON line (`legs`), each bracketed by barr
        list size swept over 1/4/8/16, payload bit error rate and frames/s.
 
 Extra objects:
-  roofline      es_xcorr32_kernel in the timed c3 leg: algorithmic bytes per launch (16 136 B per 2 048-sample window,
-                SURVEY.md section 8d) / mean launch duration, against the 8 TB/s HBM peak.
-  roofline_c2   the same kernel on the 1 024-record launch of the timed headline steps (9 472 B per record; a 9.7 MB
-                launch is latency-bound and lives in L2 / Infinity Cache -- reported, not the bandwidth figure).
+  roofline      es_xcorr32_kernel<17,2048> in the timed c3_unfused leg: algorithmic bytes per launch (16 136 B per 2 048-sample
+                window) / mean launch duration, against the 8 TB/s HBM peak; `traffic` from the committed PMC passes.
+  roofline_fused  the fused sync kernel in the timed c3 leg (8 192 + 150 B per window): LDS- and float64-bound, reported for completeness.
   roofline_scl  the kernel that dominates the time (list decoder): vector instructions per frame (PMC, profiles/) x
                 frames/s against the FP64 vector issue peak.
   cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") timed on this host (rank 0, N = 1 only).
