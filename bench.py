@@ -70,9 +70,10 @@ def parse_args(argv=None):
     ap.add_argument("--list-size", type=int, default=8)
     ap.add_argument("--legs", default="auto", help="comma list of c3,c4,c5 (auto: all at N = 1, c4 at N > 1; none: headline only)")
     ap.add_argument("--c3-windows", type=int, default=65536)
-    ap.add_argument("--c3-steps", type=int, default=5)
+    ap.add_argument("--c3-steps", type=int, default=8)
     ap.add_argument("--c4-frames", type=int, default=1 << 20, help="total frames of the strong-scaling leg (all ranks together)")
-    ap.add_argument("--c4-chunk", type=int, default=131072)
+    ap.add_argument("--c4-chunk", type=int, default=65536)
+    ap.add_argument("--big-lanes", type=int, default=2, help="pipeline lanes of the c3 / c4 legs (launches of 65 536 records)")
     ap.add_argument("--c5-frames", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on fewer GPUs)")
@@ -307,7 +308,23 @@ def run_rank(a) -> None:
         wl3 = (f"C3: {Bw} windows of 2048 float32 samples, one frame each (ctr = i, resampled by U[0.95,1.05] with linear interpolation, uniform "
                f"offset, AWGN at -15 dB SNR), generated on the device; band-pass -> float32 NCC screen + exact median/MAD threshold + NMS/top-5 "
                f"-> _llr at the detected peak -> SCL-{L} -> selection")
-        dt3, xf_ms, stage_ms, (pk, npk, flags, payload, ok) = c3_run(True, a.c3_steps)
+        _dt_seq, xf_ms, stage_ms, (pk, npk, flags, payload, ok) = c3_run(True, 2)          # sequential pass: stage breakdown, reference results
+        # the timed c3 leg: the same pass through the lane pipeline -- step k on lane k mod 2, so that the front end of one
+        # step runs beside the list decoder of the other (the list decoder's blocks are not persistent: wave slots free up
+        # as it proceeds)
+        pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes)
+        def c3_lane_step():
+            sy, _llr, scl, _done = pipe3.submit(win, band3, pn3, start="peak", select=True)
+            return sy, scl
+        c3_lane_step(); c3_lane_step(); torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(a.c3_steps):
+            sy3, scl3 = c3_lane_step()
+        barrier()
+        dt3 = time.perf_counter() - t0
+        same_lane = bool(torch.equal(sy3.peaks, pk) and torch.equal(sy3.npeaks, npk) and torch.equal(scl3.selected[0], payload) and torch.equal(scl3.selected[1], ok))
+        del pipe3, sy3, scl3
         found = int(((pk[:, :5] - off[:, None]).abs() <= 2).any(dim=1).sum().item())
         achf = (4 * 2048 + 150) * Bw / (xf_ms * 1e-3) / 1e9
         roof_fused = {"kernel": "es_xcorr32_kernel<17,2048,FUSED> (es_sync_fused_batch: screen row kept in LDS, threshold and peaks settled in the same kernel)",
@@ -316,9 +333,10 @@ def run_rank(a) -> None:
                       "note": "8 192 B of samples in + <= 150 B out per window (SURVEY 8d fused figure); this kernel is bound by LDS passes and "
                               "float64 re-evaluations, not by HBM -- it exists to take 2 x 7 944 B per window of screen traffic and two launches away",
                       "where": f"HIP events around the launch inside the timed c3 leg ({a.c3_steps} steps)"}
-        out_legs["c3"] = {"workload": wl3 + " [sync: es_sync_fused_batch]",
+        out_legs["c3"] = {"workload": wl3 + f" [sync: es_sync_fused_batch; steps alternate between {a.big_lanes} pipeline lanes]",
                           "value": Bw * a.c3_steps / dt3, "unit": "windows/s", "steps": a.c3_steps, "ms_per_step": 1e3 * dt3 / a.c3_steps,
-                          "stage_ms": stage_ms, "float64_redo_records": int(flags.sum().item()),
+                          "stage_ms_one_step_alone": stage_ms, "results_identical_to_the_sequential_pass": same_lane,
+                          "records_settled_by_the_exact_float64_row": int((flags != 0).sum().item()),
                           "windows_with_a_top5_peak_within_2_samples_of_the_true_offset": found,
                           "fallback_records": int(((npk >> 30) & 1).sum().item())}
         # the same pass with the screen going through HBM (es_xcorr32_batch + es_pick_exact_batch): the leg `roofline` is taken from
@@ -368,14 +386,18 @@ def run_rank(a) -> None:
         peak4 = torch.empty(n4, dtype=torch.int32, device=dev)
         chunk = max(1, min(a.c4_chunk, n4))
 
+        pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes)
+
         def c4_pass(limit=None):
             for c0 in range(0, n4 if limit is None else min(n4, limit), chunk):
                 c1 = min(n4, c0 + chunk)
-                sy, llr, scl = eng.decode_batch(frames4[c0:c1], band4[c0:c1], pn4[c0:c1], list_size=L)
-                p, o, _w = eng.select(scl)
-                payload4[c0:c1] = p; ok4[c0:c1] = o; peak4[c0:c1] = sy.peaks[:, 0]
+                sy, _llr, scl, _done = pipe4.submit(frames4[c0:c1], band4[c0:c1], pn4[c0:c1], select=True)
+                with torch.cuda.stream(pipe4.lane_streams[(pipe4._k - 1) % pipe4.lanes]):     # <= 64 B per frame kept, on the lane's stream
+                    payload4[c0:c1] = scl.selected[0]; ok4[c0:c1] = scl.selected[1]; peak4[c0:c1] = sy.peaks[:, 0]
+                del sy, _llr, scl
+            pipe4.synchronize()
 
-        c4_pass(limit=chunk)                               # warm-up: one chunk
+        c4_pass(limit=chunk * a.big_lanes)                 # warm-up: one chunk per lane
         barrier()
         t0 = time.perf_counter()
         c4_pass()
@@ -389,7 +411,7 @@ def run_rank(a) -> None:
             dist.all_reduce(cks); dist.all_reduce(good)
         out_legs["c4"] = {"workload": f"C4: {T4} clean 1215-sample frames in total (ctr 0..{T4 - 1}, generated on the device), sharded contiguously over "
                                       f"{world} rank(s); schedule (153 B/ctr) derived on rank 0 and broadcast; sync + _llr(start 0) + SCL-{L} + selection "
-                                      f"in chunks of {chunk}",
+                                      f"in launches of {chunk} frames on {a.big_lanes} pipeline lanes",
                           "value": T4 / dt4, "unit": "frames/s", "scaling": "strong", "seconds": dt4, "frames_total": T4,
                           "frames_per_rank": n4, "schedule_broadcast_s": bcast_s, "schedule_bytes": T4 * 153,
                           "value_incl_broadcast": T4 / (dt4 + bcast_s), "checksum": int(cks.item()),

@@ -58,6 +58,11 @@ es_ctx* es_create(int device, int list_size_max)
         es_destroy(ctx);
         return nullptr;
     }
+    if (hipMalloc(&ctx->d_slot_bits, 64 * sizeof(unsigned)) != hipSuccess || hipMemset(ctx->d_slot_bits, 0, 64 * sizeof(unsigned)) != hipSuccess) {
+        g_create_err = "device allocation of the slab slot bitmap failed";
+        es_destroy(ctx);
+        return nullptr;
+    }
     ctx->wide_scratch_bytes = es_scl_wide_scratch_bytes(ctx, &ctx->wide_slots);
     if (ctx->wide_scratch_bytes && hipMalloc(&ctx->d_wide_scratch, ctx->wide_scratch_bytes) != hipSuccess) {
         g_create_err = "device allocation of the wide-list SCL scratch slab failed";
@@ -76,6 +81,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_data_pos) (void)hipFree(ctx->d_data_pos);
     if (ctx->d_exp_tab) (void)hipFree(ctx->d_exp_tab);
     if (ctx->d_scl_scratch) (void)hipFree(ctx->d_scl_scratch);
+    if (ctx->d_slot_bits) (void)hipFree(ctx->d_slot_bits);
     if (ctx->d_ws_corr) (void)hipFree(ctx->d_ws_corr);
     if (ctx->d_wide_scratch) (void)hipFree(ctx->d_wide_scratch);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);

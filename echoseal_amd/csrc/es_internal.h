@@ -34,6 +34,7 @@ struct es_ctx {
     uint64_t* d_exp_tab = nullptr;                    /* [256] */
     /* scratch */
     double* d_scl_scratch = nullptr;  size_t scl_scratch_bytes = 0;
+    unsigned* d_slot_bits = nullptr;  /* bitmap of the slab slots of es_scl_multi_kernel (one bit per resident block) */
     double* d_ws_corr = nullptr;      size_t ws_corr_bytes = 0;
     void*   d_wide_scratch = nullptr; size_t wide_scratch_bytes = 0; int wide_slots = 0;   /* list sizes 64..256 */
     uint8_t* d_sbox = nullptr;        /* AES S-box (es_schedule_batch) */

@@ -30,6 +30,7 @@ struct SclArgs {
     const uint16_t* data_pos;
     const uint64_t* exp_tab;
     double* scratch;
+    unsigned* slot_bits; int n_slots, slot_words;   // multi-frame kernel: bitmap of slab slots (one per resident block)
     uint8_t* hard_info; uint8_t* hard_ok;
     uint8_t* cand_info; double* cand_metric; uint8_t* cand_ok; int32_t* ncand;
     int skip_if_hard_ok;

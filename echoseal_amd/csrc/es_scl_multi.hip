@@ -11,10 +11,12 @@
 // advance in lock step (the schedule depends on the leaf index only); a sort ranks a path against the
 // candidates of its own frame.
 //
-// LDS per wave is 17 KB (tree depths 5..7, partial sums, nibble-packed trace-back), two 4-wave blocks per CU (a block
-// then always covers the four SIMDs of its CU, which also lets launches from different streams share a CU evenly):
-// two waves = 2*FR frames per SIMD.  Tree depths 1..4 live in the L2-resident scratch slab, depths 8..10 in
-// registers.  Reference lines as in es_scl.hip (rtwm/fastpolar.py:254-359).
+// LDS per wave is 9.9 KB (tree depths 6..7, partial sums, windowed trace-back), three 4-wave blocks per CU (a block always
+// covers the four SIMDs of its CU): three waves = 3*FR frames per SIMD, <= 168 VGPRs.  Tree depths 1..5 live in the scratch
+// slab, depths 8..10 in registers.  Blocks are NOT persistent: a wave decodes one group of FR frames and leaves, so that
+// kernels of other streams (the front end of the next batch) get wave slots as this launch proceeds; the block's part of
+// the slab is a slot claimed from a bitmap at block start and released at its end, which also lets concurrent launches
+// of one context share the slab.  Reference lines as in es_scl.hip (rtwm/fastpolar.py:254-359).
 //
 // Build with -ffp-contract=off: every rounding step in es_math.h is explicit.
 #include "es_scl_common.h"
@@ -79,13 +81,39 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
     const int pl = path % L;                       // path within the frame
     const int fp0 = fr * L;                        // first path of the frame
     MWave<L>& W = s_wave[wv];
+    // ---- claim a slab slot for this block (bit per slot; the launch never has more resident blocks than slots)
+    __shared__ int s_slot;
+    if (threadIdx.x == 0) {
+        int slot = -1;
+        unsigned w = blockIdx.x % (unsigned)a.slot_words;
+        for (int tries = 0; slot < 0 && tries < (1 << 22); ++tries) {
+            const unsigned v = __hip_atomic_load(&a.slot_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned valid = (w == (unsigned)a.slot_words - 1 && (a.n_slots & 31)) ? ((1u << (a.n_slots & 31)) - 1u) : 0xffffffffu;
+            const unsigned freeb = ~v & valid;
+            if (freeb) {
+                const int bit = __ffs(freeb) - 1;
+                const unsigned old = atomicOr(&a.slot_bits[w], 1u << bit);
+                if (!(old & (1u << bit))) slot = (int)(w * 32u) + bit;
+            } else {
+                w = (w + 1u) % (unsigned)a.slot_words;
+                if (tries > 64) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        s_slot = slot;
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot < 0) {                                                    // cannot happen (residency <= slots, see the launcher); never spin
+        constexpr int FRq = MNP / L;                                    // forever, and never fail silently: the frames read ncand = -1
+        for (long long ff = ((long long)blockIdx.x * MWPB + (threadIdx.x >> 6)) * FRq + (threadIdx.x & 63); (threadIdx.x & 63) < FRq && ff < a.B; ff += a.B) a.ncand[ff] = -1;
+        return;
+    }
     const long long wave_id = (long long)blockIdx.x * MWPB + wv;
-    const long long n_waves = (long long)gridDim.x * MWPB;
-    double* const scr = a.scratch + wave_id * (long long)(MNP * MGSLOT);
+    double* const scr = a.scratch + ((long long)slot * MWPB + wv) * (long long)(MNP * MGSLOT);
     const uint64_t* const tab = s_exp;
     const long long n_groups = (a.B + FR - 1) / FR;
 
-    for (long long g = wave_id; g < n_groups; g += n_waves) {
+    for (long long g = wave_id; g < n_groups; g += (long long)gridDim.x * MWPB) {          // one group per wave (grid = groups / 4)
         const long long f_raw = g * FR + fr;
         const bool f_valid = f_raw < a.B;
         const long long f = f_valid ? f_raw : a.B - 1;          // a missing frame mirrors the last one (never stored)
@@ -506,6 +534,10 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
         if (q == 0 && pl == 0 && f_store) a.ncand[f] = cnt;
         wave_fence_lds();
     }
+    // ---- release the slot: every wave's slab stores are done (and performed) before the bit clears
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAnd(&a.slot_bits[slot >> 5], ~(1u << (slot & 31)));
 }
 
 template <int L>
@@ -513,14 +545,15 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
 {
     constexpr int FR = MNP / L;
     const long long groups = (B + FR - 1) / FR;
-    long long blocks = (groups + MWPB - 1) / MWPB;
-    const long long max_blocks = (long long)ctx->num_cu * MMINW;    // LDS and registers admit MMINW blocks per CU
-    if (blocks > max_blocks) blocks = max_blocks;
-    if ((size_t)blocks * MWPB * MNP * MGSLOT * sizeof(double) > ctx->scl_scratch_bytes) {
+    const long long blocks = (groups + MWPB - 1) / MWPB;          // one group per wave; the hardware keeps <= MMINW blocks per CU resident
+    const int n_slots = ctx->num_cu * MMINW;
+    if ((size_t)n_slots * MWPB * MNP * MGSLOT * sizeof(double) > ctx->scl_scratch_bytes || !ctx->d_slot_bits) {
         ctx->err = "es_scl_batch: scratch slab too small for the multi-frame kernel"; return ES_ENOMEM;
     }
+    if (blocks >= (1LL << 31)) { ctx->err = "es_scl_batch: batch too large for one launch"; return ES_EINVAL; }
     SclArgs a = a0;
     a.scratch = ctx->d_scl_scratch;
+    a.slot_bits = ctx->d_slot_bits; a.n_slots = n_slots; a.slot_words = (n_slots + 31) / 32;
     hipLaunchKernelGGL(es_scl_multi_kernel<L>, dim3((unsigned)blocks), dim3(64 * MWPB), 0, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;

@@ -487,7 +487,10 @@ class DecodePipeline:
         self._k = 0
 
     def submit(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *,
-               start: torch.Tensor | None = None, xcorr_events=None):
+               start: torch.Tensor | None = None, xcorr_events=None, select: bool = False):
+        """Enqueue one batch.  start: frame starts [B] (None = 0; "peak" = the first detected peak of each record, lanes only);
+        select (lanes only): also run the candidate selection (es_select_batch, validator None) on the lane's stream --
+        the result is attached to the returned SclResult as `.selected = (payload, ok, which)`."""
         eng = self.eng
         if frames.shape[1] - 62 > eng.FAST_MAX_LAGS:
             raise ValueError("DecodePipeline serves frame-sized records (use RxEngine.decode_batch for long captures)")
@@ -503,8 +506,12 @@ class DecodePipeline:
                 thr, peaks, npeaks, flags = e.sync_fused(y, y32, band)        # correlation screen + exact picking, one kernel
                 if xcorr_events is not None:
                     xcorr_events[1].record()
+                if isinstance(start, str):                                    # "peak": demodulate at the first detected peak
+                    start = peaks[:, 0].clamp(min=0).contiguous()
                 llr = e.llr(y, band, pn_rows, start=start, variant=0)
                 scl = e.scl(llr, list_size=self.list_size, skip_if_hard_ok=True)
+                if select:
+                    scl.selected = e.select(scl)
                 done = torch.cuda.Event()
                 done.record()
             for t in (frames, band, pn_rows):
