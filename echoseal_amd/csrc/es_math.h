@@ -364,7 +364,8 @@ ES_HD double es_polar_f(double a, double b, const uint64_t* tab)
 /* rtwm/fastpolar.py:26-29  _g_function:  b + (1 - 2u) * a  */
 ES_HD double es_polar_g(double a, double b, uint32_t u)
 {
-    return b + (1.0 - 2.0 * (double)u) * a;
+    /* (1 - 2u) is exactly +1 or -1 and (+-1) * a is exactly +-a: flipping the sign bit gives the same addend */
+    return b + es_u2d(es_d2u(a) ^ ((uint64_t)(u & 1u) << 63));
 }
 
 /* rtwm/fastpolar.py:32-40  _metric_penalty (glibc-exact flavour; see DESIGN.md "penalty") */
