@@ -374,6 +374,11 @@ int es_set_option(es_ctx* ctx, const char* name, int value)
         ctx->scl_multi = value;
         return ES_OK;
     }
+    if (std::strcmp(name, "scl_lanes") == 0) {
+        if (value != 0 && value != 2 && value != 4) return fail(ctx, ES_EINVAL, "es_set_option: scl_lanes takes 0 (by batch size), 2 or 4");
+        ctx->scl_lanes = value;
+        return ES_OK;
+    }
     return fail(ctx, ES_EINVAL, "es_set_option: unknown option");
 }
 

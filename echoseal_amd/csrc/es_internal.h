@@ -43,6 +43,7 @@ struct es_ctx {
     bool pick_attr_set = false;       /* per-device kernel attributes already raised for this context's device */
     unsigned wide_attr_mask = 0;      /* bit per wide-list kernel instantiation (64 / 128 / 256) */
     /* tuning (es_set_option) */
+    int scl_lanes = 0;                /* lanes per path of the multi-frame list decoder: 4 (16 paths per wave), 2 (32 paths per wave), 0 = by batch size */
     int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
 };
 

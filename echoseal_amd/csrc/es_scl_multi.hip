@@ -23,13 +23,20 @@
 
 namespace {
 
-constexpr int MP = 4;                              // lanes per path
-constexpr int MNP = 16;                            // paths per wave
-constexpr int MLGP = 2;                            // log2(MP)
-constexpr int MRD = NLEV - MLGP;                   // depths MRD..10 (sizes 4, 2, 1) live in registers
-constexpr int MGDEPTH = 5;                         // depths 1..5 live in global scratch
-constexpr int MGSLOT = 512 + 256 + 128 + 64 + 32;  // doubles per path slot in global scratch
-constexpr int MROW = 36;                           // depths 6..7 at [S, 2S), S = 16, 8; + 4 pad: a path's row starts 8 banks after its neighbour's (16 paths x 4 lanes read conflict-free)
+// Lanes per path P: 4 (16 paths = 16/L frames per wave) or 2 (32 paths = 32/L frames per wave).  With two lanes per path
+// the leaf-level f (two softplus terms) fills both lanes and only the leaf penalties run half empty: 11.3 k softplus
+// lane-slots per path and decode instead of 13.3 k; the price is twice the per-wave state (LDS, slab).
+template <int PP>
+struct MCfg {
+    static constexpr int P = PP;                                   // lanes per path
+    static constexpr int NP = 64 / PP;                             // paths per wave
+    static constexpr int LGP = (PP == 4) ? 2 : 1;                  // log2(P)
+    static constexpr int RD = NLEV - LGP;                          // depths RD..10 (sizes P .. 1) live in registers
+    static constexpr int GDEPTH = (PP == 4) ? 5 : 6;               // depths 1..GDEPTH live in the global scratch slab
+    static constexpr int GSLOT = N - (N >> GDEPTH);                // doubles per path slot in the slab (992 / 1008)
+    static constexpr int ROW = 2 * (N >> (GDEPTH + 1)) + 4;        // LDS row: depths GDEPTH+1 .. RD-1 at [S, 2S); + 4 pad (bank spread between paths)
+    static constexpr bool TBW_GLOBAL = (PP == 2);                  // trace-back windows in the slab instead of LDS (LDS budget: three blocks per CU)
+};
 constexpr int MWIN = KINFO / 32;                   // trace-back windows of 32 information bits
 constexpr int MWPB = 4;                            // waves per block
 #ifndef ES_MULTI_MINW
@@ -42,10 +49,12 @@ constexpr int MWPB = 4;                            // waves per block
 #define ES_MULTI_PREFETCH 0                         /* next pair of parents loaded ahead: measured slower (1.51 M against 1.75 M frames/s) */
 #endif
 constexpr int MMINW = ES_MULTI_MINW;
+template <int PP> constexpr int mslab_doubles() { return MCfg<PP>::NP * MCfg<PP>::GSLOT + (MCfg<PP>::TBW_GLOBAL ? MWIN * MCfg<PP>::NP / 2 : 0); }   // per wave
 
-template <int L>
+template <int L, int PP>
 struct MWave {
-    double   alphaS[MNP][MROW];
+    static constexpr int MNP = MCfg<PP>::NP;
+    double   alphaS[MNP][MCfg<PP>::ROW];
     double   candm[2 * MNP];                       // frame fr: [2*L*fr, 2*L*(fr+1))
     uint32_t betaL[MNP][32];                       // left-sibling partial sums, block of S bits at bit S
     union {                                        // curb lives inside the bit loop, outb before and after it
@@ -53,21 +62,23 @@ struct MWave {
         uint8_t  outb[MNP][56];
     };
     uint32_t hardw[32];
-    uint32_t tbw[MWIN][MNP];                       // trace-back by windows of 32 information bits: the window's bits (first = MSB) ...
+    uint32_t tbw[MCfg<PP>::TBW_GLOBAL ? 1 : MWIN][MNP];   // trace-back by windows of 32 information bits: the window's bits (first = MSB) ...
     uint8_t  tba[MWIN][MNP];                       // ... and the path (within the frame) this path descended from at the window's start
     uint8_t  sel[MNP];
 };
 
-template <int L>
-__global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_kernel(SclArgs a)
+template <int L, int PP>
+__global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void es_scl_multi_kernel(SclArgs a)
 {
-    constexpr int P = MP, LGP = MLGP, RD = MRD;
+    using C = MCfg<PP>;
+    constexpr int P = C::P, LGP = C::LGP, RD = C::RD, MNP = C::NP, MGDEPTH = C::GDEPTH, MGSLOT = C::GSLOT;
     constexpr int FR = MNP / L;                    // frames per wave
     constexpr int FL = 64 / FR;                    // lanes per frame
     static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16, "lists of at most 16 paths");
+    static_assert(PP == 2 || PP == 4, "two or four lanes per path");
     __shared__ __attribute__((aligned(16))) uint64_t s_exp[ES_EXP_TAB_WORDS];
     __shared__ uint16_t s_dpos[KINFO];
-    __shared__ MWave<L> s_wave[MWPB];
+    __shared__ MWave<L, PP> s_wave[MWPB];
 
     for (int i = threadIdx.x; i < ES_EXP_TAB_WORDS; i += blockDim.x) s_exp[i] = a.exp_tab[i];
     for (int i = threadIdx.x; i < KINFO; i += blockDim.x) s_dpos[i] = a.data_pos[i];
@@ -75,12 +86,12 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int path = lane / P;                     // 0..15 within the wave
+    const int path = lane / P;                     // 0..MNP-1 within the wave
     const int q = lane % P;
     const int fr = path / L;                       // frame within the wave
     const int pl = path % L;                       // path within the frame
     const int fp0 = fr * L;                        // first path of the frame
-    MWave<L>& W = s_wave[wv];
+    MWave<L, PP>& W = s_wave[wv];
     // ---- claim a slab slot for this block (bit per slot; the launch never has more resident blocks than slots)
     __shared__ int s_slot;
     if (threadIdx.x == 0) {
@@ -104,12 +115,13 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
     __syncthreads();
     const int slot = s_slot;
     if (slot < 0) {                                                    // cannot happen (residency <= slots, see the launcher); never spin
-        constexpr int FRq = MNP / L;                                    // forever, and never fail silently: the frames read ncand = -1
+        constexpr int FRq = MCfg<PP>::NP / L;                           // forever, and never fail silently: the frames read ncand = -1
         for (long long ff = ((long long)blockIdx.x * MWPB + (threadIdx.x >> 6)) * FRq + (threadIdx.x & 63); (threadIdx.x & 63) < FRq && ff < a.B; ff += a.B) a.ncand[ff] = -1;
         return;
     }
     const long long wave_id = (long long)blockIdx.x * MWPB + wv;
-    double* const scr = a.scratch + ((long long)slot * MWPB + wv) * (long long)(MNP * MGSLOT);
+    double* const scr = a.scratch + ((long long)slot * MWPB + wv) * (long long)mslab_doubles<PP>();
+    uint32_t* const tbw_g = reinterpret_cast<uint32_t*>(scr + MNP * MGSLOT);          // P = 2: trace-back windows [MWIN][MNP]
     const uint64_t* const tab = s_exp;
     const long long n_groups = (a.B + FR - 1) / FR;
 
@@ -410,11 +422,11 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
                 if (is_cand) W.candm[2 * fp0 + cl] = m;
                 wave_fence_lds();
                 const int nc = 2 * cnt;
-                constexpr int G = P / 2;                             // lanes sharing one candidate
+                constexpr int G = (P >= 2) ? P / 2 : 1;             // lanes sharing one candidate
                 constexpr int SPAN = (2 * L + G - 1) / G;            // candidates each of them compares against
                 const int cb = q & 1;
-                double mc;                                           // metric of candidate 2*pl + cb: lane (path, q & 1)
-                {
+                double mc = m;                                       // metric of candidate 2*pl + cb: lane (path, q & 1) -- the lane itself when P = 2
+                if constexpr (P == 4) {
                     uint64_t u; __builtin_memcpy(&u, &m, 8);
                     const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)u, 0x44, 0xf, 0xf, true);          // quad_perm [0,1,0,1]
                     const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), 0x44, 0xf, 0xf, true);
@@ -424,13 +436,13 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
                 const int cc_ = 2 * pl + cb;
                 const int kk0 = (q >> 1) * SPAN;
                 int rank = 0;
-                #pragma unroll
-                for (int u = 0; u < SPAN; ++u) {
+                #pragma unroll 8
+                for (int u = 0; u < SPAN; ++u) {                     // (at most eight metrics in flight: registers)
                     const int k = kk0 + u;
                     const double mk = W.candm[2 * fp0 + (k < 2 * L ? k : 0)];
                     rank += ((k < nc) && ((mk < mc) || (mk == mc && k < cc_))) ? 1 : 0;
                 }
-                rank += xor_lanes_b32<2>(rank, lane);
+                if constexpr (P == 4) rank += xor_lanes_b32<2>(rank, lane);
                 const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= L: lists of any size run on the next power of two's kernel
                 if (is_cand && rank < keep) W.sel[fp0 + rank] = (uint8_t)cl;
                 wave_fence_lds();
@@ -455,7 +467,10 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
                     const uint32_t packed = __shfl((int)((info_idx & 31) == 0 ? 0u : hist), parent * P);
                     anc = (uint32_t)__shfl((int)anc_own, parent * P);
                     hist = (packed << 1) | bit;
-                    if ((info_idx & 31) == 31 && q == 0) { W.tbw[info_idx >> 5][path] = hist; W.tba[info_idx >> 5][path] = (uint8_t)anc; }
+                    if ((info_idx & 31) == 31 && q == 0) {
+                        if constexpr (C::TBW_GLOBAL) tbw_g[(info_idx >> 5) * MNP + path] = hist; else W.tbw[info_idx >> 5][path] = hist;
+                        W.tba[info_idx >> 5][path] = (uint8_t)anc;
+                    }
                 }
                 cnt = keep;
                 ++info_idx;
@@ -505,6 +520,7 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
         }
 
         // ---------------- final ordering (fastpolar.py:335), trace-back, CRC -- per frame
+        if constexpr (C::TBW_GLOBAL) wave_fence_global();               // the windows written to the slab are read back by other lanes
         if (q == 0) W.candm[path] = metric;
         wave_fence_lds();
         int rank = 0;
@@ -515,7 +531,7 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
         if (q == 0 && pl < cnt) {
             int cur = pl;
             for (int w = MWIN - 1; w >= 0; --w) {
-                const uint32_t word = W.tbw[w][fp0 + cur];                   // information bits 32w .. 32w+31, first = MSB
+                const uint32_t word = C::TBW_GLOBAL ? tbw_g[w * MNP + fp0 + cur] : W.tbw[w][fp0 + cur];   // information bits 32w .. 32w+31, first = MSB
                 cur = (int)W.tba[w][fp0 + cur];
                 W.outb[path][4 * w + 0] = (uint8_t)(word >> 24); W.outb[path][4 * w + 1] = (uint8_t)(word >> 16);
                 W.outb[path][4 * w + 2] = (uint8_t)(word >> 8);  W.outb[path][4 * w + 3] = (uint8_t)word;
@@ -540,21 +556,21 @@ __global__ __launch_bounds__(64 * MWPB, (L <= 8 ? MMINW : 1)) void es_scl_multi_
     if (threadIdx.x == 0) atomicAnd(&a.slot_bits[slot >> 5], ~(1u << (slot & 31)));
 }
 
-template <int L>
+template <int L, int PP>
 int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
 {
-    constexpr int FR = MNP / L;
+    constexpr int FR = MCfg<PP>::NP / L;
     const long long groups = (B + FR - 1) / FR;
     const long long blocks = (groups + MWPB - 1) / MWPB;          // one group per wave; the hardware keeps <= MMINW blocks per CU resident
     const int n_slots = ctx->num_cu * MMINW;
-    if ((size_t)n_slots * MWPB * MNP * MGSLOT * sizeof(double) > ctx->scl_scratch_bytes || !ctx->d_slot_bits) {
+    if ((size_t)n_slots * MWPB * mslab_doubles<PP>() * sizeof(double) > ctx->scl_scratch_bytes || !ctx->d_slot_bits) {
         ctx->err = "es_scl_batch: scratch slab too small for the multi-frame kernel"; return ES_ENOMEM;
     }
     if (blocks >= (1LL << 31)) { ctx->err = "es_scl_batch: batch too large for one launch"; return ES_EINVAL; }
     SclArgs a = a0;
     a.scratch = ctx->d_scl_scratch;
     a.slot_bits = ctx->d_slot_bits; a.n_slots = n_slots; a.slot_words = (n_slots + 31) / 32;
-    hipLaunchKernelGGL(es_scl_multi_kernel<L>, dim3((unsigned)blocks), dim3(64 * MWPB), 0, st, a);
+    hipLaunchKernelGGL((es_scl_multi_kernel<L, PP>), dim3((unsigned)blocks), dim3(64 * MWPB), 0, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
@@ -563,7 +579,8 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
 
 size_t es_scl_multi_scratch_bytes(const es_ctx* ctx)
 {
-    return (size_t)ctx->num_cu * MMINW * MWPB * MNP * MGSLOT * sizeof(double);
+    const size_t per_wave = mslab_doubles<2>() > mslab_doubles<4>() ? mslab_doubles<2>() : mslab_doubles<4>();
+    return (size_t)ctx->num_cu * MMINW * MWPB * per_wave * sizeof(double);
 }
 
 int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
@@ -579,12 +596,16 @@ int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int 
     a.skip_if_hard_ok = skip_if_hard_ok;
     a.lsz = L;
     int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
+    // lanes per path (es_set_option "scl_lanes": 2, 4, or 0 = choose): two lanes per path need fewer instructions per frame
+    // (measured 2.15 M against 2.03 M frames/s at 65 536 frames) but a wave then carries 32/L frames and takes 1.6x as long, so
+    // the choice falls on it once the batch gives every wave slot of the chip at least two such waves
+    const bool two = ctx->scl_lanes == 2 || (ctx->scl_lanes == 0 && (long long)B * LP / 32 >= 2LL * ctx->num_cu * MMINW * MWPB);
     switch (LP) {
-        case 1: return launch_multi<1>(ctx, a, B, st);
-        case 2: return launch_multi<2>(ctx, a, B, st);
-        case 4: return launch_multi<4>(ctx, a, B, st);
-        case 8: return launch_multi<8>(ctx, a, B, st);
-        case 16: return launch_multi<16>(ctx, a, B, st);
-        default: ctx->err = "the 16-paths-per-wave list decoder serves list sizes 1, 2, 4, 8, 16"; return ES_EINVAL;
+        case 1: return two ? launch_multi<1, 2>(ctx, a, B, st) : launch_multi<1, 4>(ctx, a, B, st);
+        case 2: return two ? launch_multi<2, 2>(ctx, a, B, st) : launch_multi<2, 4>(ctx, a, B, st);
+        case 4: return two ? launch_multi<4, 2>(ctx, a, B, st) : launch_multi<4, 4>(ctx, a, B, st);
+        case 8: return two ? launch_multi<8, 2>(ctx, a, B, st) : launch_multi<8, 4>(ctx, a, B, st);
+        case 16: return two ? launch_multi<16, 2>(ctx, a, B, st) : launch_multi<16, 4>(ctx, a, B, st);
+        default: ctx->err = "the multi-frame list decoder serves list sizes up to 16"; return ES_EINVAL;
     }
 }

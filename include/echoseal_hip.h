@@ -209,7 +209,9 @@ int es_softplus_batch(es_ctx* ctx, const double* t_dev, int64_t n, double* out_d
 
 /* Tuning knobs; results never depend on them.  "scl_multi": -1 (default) lets es_scl_batch choose between one
  * frame per wavefront and 16/L frames per wavefront (list sizes <= 8; better lane use at the bottom of the LLR
- * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.                                   */
+ * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.  "scl_lanes": lanes per path of the latter
+ * kernel -- 4 (16 paths per wavefront), 2 (32 paths per wavefront: fewer instructions per frame, longer wavefronts; for
+ * batches of tens of thousands of frames) or 0 (default: chosen by batch size).                                     */
 int es_set_option(es_ctx* ctx, const char* name, int value);
 
 /* ---- the step after the list decoder ------------------------------------------------

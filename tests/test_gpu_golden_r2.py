@@ -88,18 +88,20 @@ def test_multi_peak_records_vs_reference(engine):
             assert list(sy.peaks[0, :k].cpu().numpy()) == ref[:k], (t, name)
 
 
-@pytest.mark.parametrize("multi", [0, 1])
+@pytest.mark.parametrize("multi", [0, 1, 2])
 def test_polar_bulk_vs_reference(engine, multi):
     """1 024 LLR vectors: final SCL-8 lists bit-identical (bits, metrics, CRC flags) to the reference run on the C
-    library's exp/log1p; hard-decision shortcut and (info, ok) through es_select_batch."""
+    library's exp/log1p; hard-decision shortcut and (info, ok) through es_select_batch.  All three mappings: one frame
+    per wave (0), 16 paths x 4 lanes per wave (1), 32 paths x 2 lanes per wave (2)."""
     g = _g("polar_bulk_glibc.npz")
     llr, = _dev(engine, g["llr"])
-    engine.set_option("scl_multi", multi)
+    engine.set_option("scl_multi", 1 if multi else 0)
+    engine.set_option("scl_lanes", 2 if multi == 2 else 4)
     try:
         res = engine.scl(llr, list_size=8, skip_if_hard_ok=False)
         short = engine.scl(llr, list_size=8, skip_if_hard_ok=True)
     finally:
-        engine.set_option("scl_multi", -1)
+        engine.set_option("scl_multi", -1); engine.set_option("scl_lanes", 0)
     took = g["took_list"]
     assert np.array_equal(short.ncand.cpu().numpy() > 0, took)                   # the shortcut fires exactly where the reference's did
     assert np.array_equal(res.cand_info.cpu().numpy()[took], g["cand_info"][took])
@@ -172,11 +174,11 @@ def test_list_sizes_that_are_not_powers_of_two(engine, oracle):
     rng = np.random.default_rng(77)
     x = np.clip(rng.normal(0, 3, (40, 1024)), -12, 12).astype(np.float32)
     x[0] = 0.0; x[0, 0] = 1e-3
-    for L in (3, 7, 9, 15, 17, 31, 33, 48, 65, 127, 129, 200, 255):
-        for multi in ((0, 1) if L <= 16 else (0,)):
-            big.set_option("scl_multi", multi)
+    for L in (1, 2, 3, 4, 7, 9, 15, 16, 17, 31, 33, 48, 65, 127, 129, 200, 255):
+        for multi in ((0, 1, 2) if L <= 16 else (0,)):
+            big.set_option("scl_multi", 1 if multi else 0); big.set_option("scl_lanes", 2 if multi == 2 else 4)
             res = big.scl(torch.from_numpy(x).to(big.device), list_size=L, skip_if_hard_ok=False)
-            big.set_option("scl_multi", -1)
+            big.set_option("scl_multi", -1); big.set_option("scl_lanes", 0)
             assert res.cand_metric.shape == (40, L)
             for i in range(0, 40, 3 if L < 64 else 13):
                 nn, ci, cm, cc = oracle.scl_list(x[i].astype(np.float64), L)

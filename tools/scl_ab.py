@@ -13,8 +13,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from echoseal_amd.engine import RxEngine
     eng = RxEngine(0, list_size_max=16); rng = np.random.default_rng(0)
     base = torch.from_numpy(np.clip(rng.normal(0, 3, (4096, 1024)), -12, 12).astype(np.float32)).to(eng.device)
-    for multi in (1, 0):
-        eng.set_option("scl_multi", multi)
+    for multi in (1, 2, 0):                       # 1: four lanes per path, 2: two lanes per path, 0: one frame per wave
+        eng.set_option("scl_multi", 1 if multi else 0)
+        if multi:
+            try: eng.set_option("scl_lanes", 4 if multi == 1 else 2)
+            except Exception: continue
         for B in (1024, 4096, 16384, 65536):
             llr = base.repeat(-(-B // 4096), 1)[:B].contiguous()
             r = eng.scl(llr, list_size=8, skip_if_hard_ok=False); torch.cuda.synchronize()
