@@ -60,6 +60,7 @@ struct PwFixed;
 __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, const double* tpl, long long rec, int lane,
                               const FusedArgs& fo);
 __host__ __device__ __forceinline__ size_t xf_lds_per_wave(int ns2, int n_lags);
+__host__ __device__ __forceinline__ int xf_head_floats(int ns2);
 
 // ------------------------------------------------------------------------------------ xcorr32
 // R = lags per lane.  R = 19 (one wave per frame-sized record) moves the fewest LDS bytes per FMA and is the
@@ -82,12 +83,12 @@ void es_xcorr32_kernel(const float* __restrict__ y, long long B,
     constexpr int NS = SEG + ES_PRE_L - 1;
     constexpr int WAVES = FUSED ? XF_WAVES : XC_WAVES;
     __shared__ float s_buf[FUSED ? 1 : XC_WAVES][FUSED ? 4 : NS + 2];
-    extern __shared__ __attribute__((aligned(16))) unsigned char xf_smem[];      // FUSED: per wave [samples | screen row | PwFixed]
+    extern __shared__ __attribute__((aligned(16))) unsigned char xf_smem[];      // FUSED: per wave [samples, later the picker's PwFixed | screen row]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: item, record, band are scalar
     const int n_lags = T - (ES_PRE_L - 1);
     float* s = FUSED ? reinterpret_cast<float*>(xf_smem + wv * xf_lds_per_wave(NS + 2, n_lags)) : s_buf[wv];
-    float* const crow = s + (((NS + 2) + 3) & ~3);                            // FUSED: the record's screen row
+    float* const crow = s + xf_head_floats(NS + 2);                           // FUSED: the record's screen row
     const int nseg = (n_lags + SEG - 1) / SEG;
     const long long n_items = B * nseg;
     // non-fused: consecutive items go to consecutive waves.  Fused: a wave takes the nseg items of one record, then
@@ -202,7 +203,7 @@ void es_xcorr32_kernel(const float* __restrict__ y, long long B,
         wave_fence_lds();
         if constexpr (FUSED) {
             if (lag0 + SEG >= n_lags) {                                       // last segment: the row is complete
-                PwFixed& S = *reinterpret_cast<PwFixed*>(reinterpret_cast<unsigned char*>(crow) + (((size_t)n_lags * 4 + 15) & ~(size_t)15));
+                PwFixed& S = *reinterpret_cast<PwFixed*>(s);             // the samples are dead by now: their LDS serves the picker
                 sync_pick_row(S, crow, n_lags, fo.y64 + rec * T, tabs->tpl[bi], rec, lane, fo);
             }
         } else {
@@ -390,9 +391,16 @@ __device__ bool pw_exact_stats(PwFixed& S, int n, int k_lo, int k_hi, double d, 
     return true;
 }
 
+// LDS of one fused-sync wave: a head region that holds the staged samples while the row is computed and the picker's
+// PwFixed afterwards (never live together), then the record's screen row.
+__host__ __device__ __forceinline__ int xf_head_floats(int ns2)
+{
+    const int a = (ns2 + 3) & ~3, b = (int)((sizeof(PwFixed) + 15) & ~(size_t)15) / 4;
+    return a > b ? a : b;
+}
 __host__ __device__ __forceinline__ size_t xf_lds_per_wave(int ns2, int n_lags)
 {
-    return (size_t)((ns2 + 3) & ~3) * 4 + (((size_t)n_lags * 4 + 15) & ~(size_t)15) + sizeof(PwFixed);
+    return (size_t)xf_head_floats(ns2) * 4 + (((size_t)n_lags * 4 + 15) & ~(size_t)15);
 }
 
 // ------------------------------------------------------------------------------------ fused sync: the rare exact row

@@ -923,3 +923,24 @@ def test_c5_surrogate_list_sweep_vs_oracle(engine, oracle):
             assert list(sy.peaks[i, :k].cpu().numpy()) == list(ref[i]["peaks"][:k]) and np.array_equal(llr_h[i], ref[i]["llr"])
             info, okr, _ = oracle.polar_decode(ref[i]["llr"].astype(np.float64), L)
             assert np.packbits(info).tobytes() == payload[i].tobytes() and bool(okr) == (ok[i] == 1), (L, i)
+
+
+def test_contexts_on_two_devices():
+    """Kernel attributes (dynamic LDS above 64 KB for list size 256 and for the exact picker) are raised per context, i.e.
+    per device: a context on a second GPU of the same process works like the first.  Needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from echoseal_amd.engine import RxEngine
+    rng = np.random.default_rng(5)
+    llr = np.clip(rng.normal(0, 3, (4, 1024)), -12, 12).astype(np.float32)
+    x = rng.normal(0, 0.1, (4, 3000)).astype(np.float32); band = np.array([0, 1, 2, 3], np.uint8)
+    outs = []
+    for d in (0, 1):
+        eng = RxEngine(d, list_size_max=256)
+        r = eng.scl(torch.from_numpy(llr).to(eng.device), list_size=256, skip_if_hard_ok=False)
+        f, b = torch.from_numpy(x).to(eng.device), torch.from_numpy(band).to(eng.device)
+        y, y32 = eng.bpf2(f, b)
+        p = eng.pick_exact(eng.xcorr32(y32, b), y, b)
+        outs.append((r.cand_metric.cpu(), r.cand_info.cpu(), p[0].cpu(), p[1].cpu()))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
