@@ -73,8 +73,19 @@ class WatermarkDetector:
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(self.engine.device)
 
     # ------------------------------------------------------------------ API
+    def verify_wav(self, path: str) -> bool:
+        """verify() for a WAV file (f-4 ingest): PCM16 samples stay int16 up to the band-pass kernel (x / 32768 there: the
+        values soundfile.read hands the reference, rx_app.py:25-28)."""
+        from .audiofile import read_wav
+        samples, fs = read_wav(path)
+        return self.verify(samples, fs)
+
     def _conditioned(self, audio, fs_in: int) -> np.ndarray:
         audio = np.asarray(audio)
+        if audio.dtype == np.int16:
+            if fs_in == self.fs_target:
+                return audio                                 # ingested as int16 by the band-pass kernel
+            audio = audio.astype(np.float32) / np.float32(32768.0)
         if fs_in != self.fs_target and audio.ndim == 1 and audio.size:
             # polyphase resampling on the device (es_resample_batch): the values scipy.signal.resample_poly returns
             return self.engine.resample(audio, fs_in, self.fs_target).cpu().numpy()
@@ -96,13 +107,14 @@ class WatermarkDetector:
         by clip and band by band in the reference's order, ONE demodulate + list-decode + validate batch over all
         (peak, counter) candidates of the band, walked on the host with the reference's early return."""
         fs_list = list(fs_in) if isinstance(fs_in, (list, tuple)) else [fs_in] * len(clips)
-        signals = [np.asarray(self._conditioned(c, f)).astype(np.float32, copy=False).reshape(-1) for c, f in zip(clips, fs_list)]
+        signals = [np.asarray(self._conditioned(c, f)).reshape(-1) for c, f in zip(clips, fs_list)]
+        signals = [sg if sg.dtype == np.int16 else sg.astype(np.float32, copy=False) for sg in signals]
         order = self._band_order()
         scans: list = [None] * len(signals)
         groups: dict[int, list[int]] = {}
         for i, sgl in enumerate(signals):
-            groups.setdefault(sgl.size, []).append(i)
-        for size, idx in groups.items():
+            groups.setdefault((sgl.size, sgl.dtype == np.int16), []).append(i)
+        for (size, _is_i16), idx in groups.items():
             if size < PRE_L:                                                # rtwm/detector.py:71-73
                 continue
             for i, sc in zip(idx, self._scan_prepare([signals[i] for i in idx], order)):
@@ -123,7 +135,7 @@ class WatermarkDetector:
         import torch
         eng = self.engine
         g, nb, M = len(signals), len(bands), signals[0].size
-        x = self._dev(np.repeat(np.stack(signals), nb, axis=0), np.float32)            # row = clip * nb + band
+        x = self._dev(np.repeat(np.stack(signals), nb, axis=0), signals[0].dtype)      # row = clip * nb + band (float32, or int16 samples)
         bid = self._dev(np.tile(np.array([self._band_id(b) for b in bands]), g), np.uint8)
         sy = eng.sync_fast(x, bid) if M - (PRE_L - 1) <= eng.FAST_MAX_LAGS else eng.sync(x, bid, keep_corr=False)
         npk = (sy.npeaks.cpu().numpy() & 0xFFFF)
@@ -226,7 +238,9 @@ class WatermarkDetector:
         return sy.y[0].cpu().numpy(), float(sy.thr[0].item()), peaks
 
     def _scan_band_multi_frame(self, signal: np.ndarray, band) -> bool:
-        sig = np.asarray(signal).astype(np.float32, copy=False).reshape(-1)
+        sig = np.asarray(signal).reshape(-1)
+        if sig.dtype != np.int16:
+            sig = sig.astype(np.float32, copy=False)
         if sig.size < PRE_L:                                   # rtwm/detector.py:71-73
             return False
         return self._scan_decide(self._scan_prepare([sig], [band])[0], 0)

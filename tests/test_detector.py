@@ -136,3 +136,23 @@ def test_verify_batch_equals_sequential_verify(engine):
     assert b.verify_batch(clips, 48_000) == seq
     assert a._trace == b._trace and a._hdr_trace == b._hdr_trace and a.session_nonce == b.session_nonce
     assert len(a._trace) > 20
+
+
+@pytest.mark.gpu
+def test_verify_int16_and_wav_equal_float_path(engine, tmp_path):
+    """PCM16 ingest (f-4): verify() on int16 samples and verify_wav() on the file follow exactly the search that verify()
+    follows on the float32 samples x / 32768 (what soundfile.read gives the reference for the same file)."""
+    from echoseal_amd.audiofile import write_wav_pcm16
+    g3 = np.load(os.path.join(GOLD, "verify3s.npz"))
+    x16 = np.clip(np.round(g3["clip"][:60000].astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+    xf = x16.astype(np.float32) / np.float32(32768.0)
+    path = str(tmp_path / "clip.wav")
+    write_wav_pcm16(path, x16, 48_000)
+    traces = []
+    for how in ("float", "int16", "wav"):
+        det = WatermarkDetector(KEY, list_size=1, engine=engine); det._trace = []; det._hdr_trace = []
+        res = det.verify(xf, 48_000) if how == "float" else det.verify(x16, 48_000) if how == "int16" else det.verify_wav(path)
+        traces.append((res, det._trace, det._hdr_trace))
+    assert traces[0] == traces[1] == traces[2] and len(traces[0][1]) > 5
+    write_wav_pcm16(path, x16[:20000], 44_100)                                     # other rate: resampled on the device
+    assert WatermarkDetector(KEY, list_size=1, engine=engine).verify_wav(path) is False

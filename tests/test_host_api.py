@@ -124,3 +124,20 @@ def test_declared_limits_raise_not_implemented():
             det.verify(np.zeros(5000, np.float32), 44_100)
     # list sizes: any value >= 1 is accepted, as in the reference; the HIP kernels serve up to 256
     assert PolarCode(1024, 448, list_size=3).list_size == 3 and PolarCode(1024, 448, list_size=1000).list_size == 1000
+
+
+def test_wav_ingest_round_trip(tmp_path):
+    """f-4 ingest: a PCM16 WAV comes back as the int16 samples that were written, and x / 32768 in float32 is exactly the
+    value soundfile.read hands the reference for such a file."""
+    from echoseal_amd.audiofile import read_wav, write_wav_pcm16
+    rng = np.random.default_rng(1)
+    x = rng.integers(-32768, 32768, 5000).astype(np.int16)
+    p = str(tmp_path / "a.wav")
+    write_wav_pcm16(p, x, 48_000)
+    y, fs = read_wav(p)
+    assert fs == 48_000 and y.dtype == np.int16 and np.array_equal(x, y)
+    f = rng.uniform(-1, 1, 3000)
+    write_wav_pcm16(p, f, 44_100)
+    y, fs = read_wav(p)
+    assert fs == 44_100 and np.max(np.abs(y.astype(np.float64) / 32768.0 - f)) <= 0.5 / 32768 + 1e-12
+    assert np.array_equal((y.astype(np.float64) / 32768.0).astype(np.float32), y.astype(np.float32) / np.float32(32768.0))
