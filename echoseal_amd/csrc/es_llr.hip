@@ -1,8 +1,8 @@
 // es_llr.hip -- per-frame soft demodulation (WatermarkDetector._llr, rtwm/detector.py:296-416)
 // for gfx950: matched filter -> integer chip-shift search -> PN despread -> robust scaling.
 //
-// One 256-thread block (4 waves) per frame.  LDS holds the frame slice, the taps, the +-1 PN
-// symbols, the matched-filter window and the despread vector (~23 KB, 6 blocks per CU).
+// One WAVE per frame record, one-wave blocks (round 1 used a 256-thread block per record: ~14 block barriers and phases in
+// which three of four waves waited for the fourth -- 2.3 ms per 65 536 records against 1.4 ms now).  LDS per wave 16.5 KB.
 //
 // Numerics follow the reference's NumPy float32 data flow step by step:
 //   * matched filter: float64 accumulation of exact float32 products, ascending sample order,
@@ -25,7 +25,6 @@ namespace {
 
 constexpr int NPAY = ES_POLAR_N;
 constexpr int PAYLOAD_START = ES_PRE_L + ES_HDR_L;   // 191
-constexpr int LLR_THREADS = 256;
 constexpr int MAX_RX = NPAY + ES_MAX_TAPS;           // prefix + payload
 constexpr int MAX_WIN = NPAY + 2 * ES_MAX_TAPS + 8;  // matched-filter window
 constexpr int MF_R = 6;                              // matched-filter outputs per thread
@@ -117,7 +116,8 @@ __device__ __forceinline__ PwLane pw_lane(const PwPlan& p, int lane)
     PwLane g; g.st = st; g.ln = ln; g.full = (ln >= 8) ? ln - (ln % 8) : 0;
     return g;
 }
-__device__ __forceinline__ float wave_pairwise_sum_nonneg(const PwLane& g, int lane, const float* __restrict__ a)
+// (|a[i]| is taken on the fly: the kernel keeps no separate |win| array)
+__device__ __forceinline__ float wave_pairwise_sum_nonneg_abs(const PwLane& g, int lane, const float* __restrict__ a)
 {
     constexpr int NIT = 16;
     const int jj = lane & 3;
@@ -126,13 +126,13 @@ __device__ __forceinline__ float wave_pairwise_sum_nonneg(const PwLane& g, int l
     for (int k = 0; k < NIT; ++k) {
         const bool ok = 8 * k < g.full;
         const int idx = ok ? g.st + 8 * k + jj : 0;
-        const float u = a[idx], v = a[idx + 4];
+        const float u = __builtin_fabsf(a[idx]), v = __builtin_fabsf(a[idx + 4]);
         x0[k] = ok ? u : 0.0f; x1[k] = ok ? v : 0.0f;
     }
     #pragma unroll
     for (int k = 0; k < 7; ++k) {
         const bool ok = g.full + k < g.ln;
-        const float u = a[ok ? g.st + g.full + k : 0];
+        const float u = __builtin_fabsf(a[ok ? g.st + g.full + k : 0]);
         tl[k] = ok ? u : 0.0f;
     }
     float ra = x0[0], rb = x1[0];
@@ -231,41 +231,39 @@ __device__ float wave_median_hist_f32(uint32_t (*hist)[256], int n, int lane, F 
     return (lo + hi) / 2.0f;
 }
 
-__global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __restrict__ y, long long B,
+// ---- the demodulator: one WAVE per record ----------------------------------------------------------------------------
+// A record belongs to one wave from the first load to the last store: no block barriers.  LDS per wave is 16.5 KB -- the PN
+// symbols stay packed, |win| is taken on the fly, only the float64 prefix sums that the 2 x (2 max_shift + 1) window ends need
+// are kept, and regions are reused across phases -- and a block is one wave, so that it fits beside three resident
+// list-decoder blocks (41 KB of LDS left) and nine fit an otherwise empty CU.
+constexpr int LW_WAVES = 1;                           // one-wave blocks (16.5 KB of LDS): they fit beside three resident list-decoder blocks
+constexpr int LW_NSH = 2 * ES_MAX_TAPS + 8;          // shifts, at most
+struct LlrWaveLds {
+    union {
+        struct { float rx[MF_PAD + MAX_RX + MF_PAD]; float h[MF_PAD]; } mf;     // matched-filter inputs, zero padded
+        double pre[2][LW_NSH];                                               // prefix sums at the window ends of every shift
+        float d[NPAY];                                                        // despread values
+    } a;
+    float win[MAX_WIN];
+    union {
+        struct { double A[LW_NSH]; int cand[LW_NSH]; } sh;                    // exact-sum score per shift, candidate shifts
+        uint32_t hist[4][256];                                                // radix-select histograms of the robust statistics
+    } b;
+    uint32_t pnw[32];                                                         // payload PN bits, first = MSB of word 0
+};
+
+__global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const double* __restrict__ y, long long B,
         int T, const int32_t* __restrict__ start, const uint8_t* __restrict__ band,
         const uint8_t* __restrict__ pn_rows, int variant, const es_band_tables* __restrict__ tabs,
         float* __restrict__ llr, int32_t* __restrict__ best_s_out, float* __restrict__ score_out)
 {
-    // LDS is reused across the phases of a record (31 KB instead of 45: three blocks fit beside a resident list decoder):
-    //   region A: {s_rx, s_h} (matched filter inputs) -> s_pre (float64 prefix sums of the screen) -> s_d (despread values)
-    //   region B: s_abs (|win|, shift search) -> s_hist4 (histograms of the robust statistics)
-    constexpr int RX_N = MF_PAD + MAX_RX + MF_PAD;
-    constexpr size_t A_BYTES = (sizeof(float) * (RX_N + MF_PAD + NPAY) > sizeof(double) * (MAX_WIN + 1))
-                                   ? sizeof(float) * (RX_N + MF_PAD + NPAY) : sizeof(double) * (MAX_WIN + 1);
-    constexpr size_t B_BYTES = (sizeof(float) * MAX_WIN > sizeof(uint32_t) * 4 * 256) ? sizeof(float) * MAX_WIN : sizeof(uint32_t) * 4 * 256;
-    __shared__ __attribute__((aligned(16))) unsigned char s_regA[A_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char s_regB[B_BYTES];
-    float* const s_rx = reinterpret_cast<float*>(s_regA);             // zero padded both sides: no bounds in the tap loop
-    float* const s_h = s_rx + RX_N;
-    float* const s_d = s_h + MF_PAD;
-    double* const s_pre = reinterpret_cast<double*>(s_regA);          // float64 prefix sums of |win| (shift-search screen)
-    float* const s_abs = reinterpret_cast<float*>(s_regB);
-    uint32_t (*const s_hist4)[256] = reinterpret_cast<uint32_t (*)[256]>(s_regB);
-    __shared__ float s_pn[NPAY];
-    __shared__ float s_win[MAX_WIN];
-    __shared__ double s_A[2 * ES_MAX_TAPS + 8];      // exact-sum score per shift
-    __shared__ int    s_cand[2 * ES_MAX_TAPS + 8];   // shifts that get the float32 NumPy-order evaluation
-    __shared__ double s_wtot[4];
-    __shared__ double s_top[4][2];
-    __shared__ int    s_wcnt[4];
-    __shared__ float s_score[4][2];
-    __shared__ int   s_shift[4];
-    __shared__ float s_stats[4];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ __attribute__((aligned(16))) LlrWaveLds s_w[LW_WAVES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    LlrWaveLds& W = s_w[wv];
+    auto fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     __builtin_amdgcn_s_setprio(2);      // front-end kernel: issue ahead of a resident list-decoder wave
-
-    for (long long rec = blockIdx.x; rec < B; rec += gridDim.x) {
+    const long long stride = (long long)gridDim.x * LW_WAVES;
+    for (long long rec = (long long)blockIdx.x * LW_WAVES + wv; rec < B; rec += stride) {
         float* out = llr + rec * NPAY;
         const int st0 = start ? start[rec] : 0;
         int flen = T - st0; if (flen > ES_FRAME_LEN) flen = ES_FRAME_LEN;
@@ -274,27 +272,30 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         const int mem = ntaps - 1;
         const int npl = flen - PAYLOAD_START;                         // payload samples present
         if (st0 < 0 || npl <= 0) {                                    // detector.py:320-325
-            for (int i = tid; i < NPAY; i += LLR_THREADS) out[i] = 0.0f;
-            if (tid == 0) { if (best_s_out) best_s_out[rec] = 0; if (score_out) { score_out[2 * rec] = -1.0f; score_out[2 * rec + 1] = -1.0f; } }
+            for (int i = lane; i < NPAY; i += 64) out[i] = 0.0f;
+            if (lane == 0) { if (best_s_out) best_s_out[rec] = 0; if (score_out) { score_out[2 * rec] = -1.0f; score_out[2 * rec + 1] = -1.0f; } }
             continue;
         }
         const double* fr = y + rec * T + st0;
         const int prefix = mem < PAYLOAD_START ? mem : PAYLOAD_START; // :327
         const int nfull = prefix + npl;
-        for (int i = tid; i < MF_PAD + MAX_RX + MF_PAD; i += LLR_THREADS) {
+        for (int i = lane; i < MF_PAD + MAX_RX + MF_PAD; i += 64) {
             const int ii = i - MF_PAD;
-            s_rx[i] = (ii >= 0 && ii < nfull) ? (float)fr[PAYLOAD_START - prefix + ii] : 0.0f;
+            W.a.mf.rx[i] = (ii >= 0 && ii < nfull) ? (float)fr[PAYLOAD_START - prefix + ii] : 0.0f;
         }
-        for (int i = tid; i < MF_PAD; i += LLR_THREADS) s_h[i] = (i < ntaps) ? tabs->taps[bi][i] : 0.0f;
+        for (int i = lane; i < MF_PAD; i += 64) W.a.mf.h[i] = (i < ntaps) ? tabs->taps[bi][i] : 0.0f;
         const int n = NPAY < npl ? NPAY : npl;                        // :337
-        const uint8_t* pnr = pn_rows + rec * ES_PN_BYTES;
-        const int pn_off = (variant == 0) ? PAYLOAD_START : 0;        // :306-312
-        for (int i = tid; i < n; i += LLR_THREADS) {
-            const int bpos = pn_off + i;
-            const uint32_t bit = (pnr[bpos >> 3] >> (7 - (bpos & 7))) & 1u;
-            s_pn[i] = 2.0f * (float)bit - 1.0f;
+        if (lane < 32) {                                              // 32 PN bits per lane, MSB first, from the packed row (:306-312)
+            const uint8_t* pnr = pn_rows + rec * ES_PN_BYTES;
+            const int p0 = ((variant == 0) ? PAYLOAD_START : 0) + 32 * lane;
+            const int b0 = p0 >> 3, sh = p0 & 7;
+            uint64_t v = 0;
+            #pragma unroll
+            for (int k = 0; k < 5; ++k) v = (v << 8) | (uint64_t)((b0 + k < ES_PN_BYTES) ? pnr[b0 + k] : 0);
+            W.pnw[lane] = (uint32_t)(v >> (8 - sh));
         }
-        __syncthreads();
+        fence();
+        auto pn_sym = [&](int i) { return ((W.pnw[i >> 5] >> (31 - (i & 31))) & 1u) ? 1.0f : -1.0f; };
 
         // ---- geometry (:335-363)
         const int nmf = nfull + ntaps - 1;
@@ -311,28 +312,26 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
         if (n / 4 < guard) guard = n / 4;
         if (guard >= n) guard = n / 4 > 0 ? n / 4 : 0;
 
-        // ---- matched filter window (:334): mf[j] = sum_i rx[i] h[j-i], i ascending (= tap k = j-i
-        // descending), float64 accumulation of exact float32 products, rounded once.  Each thread
-        // owns MF_R consecutive outputs and slides a register window over the samples they share;
-        // zero padding (samples and taps) only adds exact zeros.
+        // ---- matched filter window (:334): mf[j] = sum_i rx[i] h[j-i], i ascending (= tap k = j-i descending), float64
+        // accumulation of exact float32 products, rounded once.  Each lane owns MF_R consecutive outputs per pass and slides
+        // a register window over the samples they share; zero padding (samples and taps) only adds exact zeros.
         {
-            const int k6 = ((ntaps + MF_R - 1) / MF_R) * MF_R;          // taps rounded up (extra taps are 0)
-            for (int w0 = tid * MF_R; w0 < nwin; w0 += LLR_THREADS * MF_R) {
+            const int k6 = ((ntaps + MF_R - 1) / MF_R) * MF_R;
+            for (int w0 = lane * MF_R; w0 < nwin; w0 += 64 * MF_R) {
                 const int jj0 = wstart + w0;
                 double acc[MF_R];
                 #pragma unroll
                 for (int r = 0; r < MF_R; ++r) acc[r] = 0.0;
-                // window x[r] = rx[jj0 + r - k] for the current tap k; walk k = k6-1 .. 0
-                const float* px = s_rx + MF_PAD + jj0 - (k6 - 1);
+                const float* px = W.a.mf.rx + MF_PAD + jj0 - (k6 - 1);
                 double x[2 * MF_R - 1];
                 #pragma unroll
                 for (int r = 0; r < MF_R - 1; ++r) x[r] = (double)px[r];
-                for (int kb = k6 - 1; kb >= 0; kb -= MF_R) {             // taps kb, kb-1, ..., kb-5
+                for (int kb = k6 - 1; kb >= 0; kb -= MF_R) {
                     #pragma unroll
                     for (int u = 0; u < MF_R; ++u) x[MF_R - 1 + u] = (double)px[MF_R - 1 + u];
                     #pragma unroll
                     for (int u = 0; u < MF_R; ++u) {
-                        const double hk = (double)s_h[kb - u];
+                        const double hk = (double)W.a.mf.h[kb - u];
                         #pragma unroll
                         for (int r = 0; r < MF_R; ++r) acc[r] = __builtin_fma(x[u + r], hk, acc[r]);
                     }
@@ -341,52 +340,53 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
                     px += MF_R;
                 }
                 #pragma unroll
-                for (int r = 0; r < MF_R; ++r) if (w0 + r < nwin) s_win[w0 + r] = (float)acc[r];
+                for (int r = 0; r < MF_R; ++r) if (w0 + r < nwin) W.win[w0 + r] = (float)acc[r];
             }
         }
-        __syncthreads();
+        fence();
 
-        // ---- shift search (:366-379): score(s) = mean(|win[base+s+i] * pn[i]|, i >= guard).  pn[i] is +-1, so
-        // |win * pn| == |win| exactly: the scores are NumPy pairwise sums over sliding windows of |win|, which is
-        // computed once; the PN symbols only enter at the despread.  (The sums themselves cannot slide: float32
-        // addition order is part of the result.)
-        for (int i = tid; i < nwin; i += LLR_THREADS) s_abs[i] = __builtin_fabsf(s_win[i]);
-        __syncthreads();
+        // ---- shift search (:366-379): score(s) = mean(|win[base+s+i] * pn[i]|, i >= guard).  pn[i] is +-1, so |win * pn| ==
+        // |win| exactly: the scores are NumPy pairwise sums over sliding windows of |win|.  (The sums themselves cannot slide:
+        // float32 addition order is part of the result.)  Screen: a float32 pairwise sum of non-negative terms is within
+        // (1+2^-24)^30 - 1 < 1.8e-6 (relative) of the exact sum, and the exact window sums of all shifts come from ONE float64
+        // prefix sum.  Only shifts whose exact-sum score is within SCREEN_R of the runner-up can be the winner or the runner-up
+        // that the kernel reports; those -- usually two to four of the ~260 -- get the NumPy-order float32 evaluation.  Flat or
+        // non-finite data simply leaves every shift a candidate.
         PwPlan plan;
         pw_plan_build(plan, n - guard);
         const float cnt_f = (float)(n - guard);
         const PwLane geo = pw_lane(plan, lane);
-        // Screen: a float32 pairwise sum of non-negative terms is within (1+2^-24)^30 - 1 < 1.8e-6 (relative) of the
-        // exact sum (no element passes through more than 29 additions: 15 in its accumulator, 3 combining, <= 7
-        // trailing, 4 tree levels; plus the division), and the exact window sums of all shifts come from ONE float64
-        // prefix sum.  Only shifts whose exact-sum score is within SCREEN_R of the runner-up can be the winner or the
-        // runner-up that the kernel reports; those -- usually two to four of the ~260 -- get the NumPy-order float32
-        // evaluation.  Flat or non-finite data simply leaves every shift a candidate.
         constexpr double SCREEN_R = 4e-6;
+        const int nshift = 2 * max_shift + 1;
+        const int lo_a = base - max_shift + guard, lo_b = base - max_shift + n;      // pre[lo_a + u], pre[lo_b + u] for shift index u
+        double total;
         {
-            const int chunk = (nwin + LLR_THREADS - 1) / LLR_THREADS;
-            const int j0 = tid * chunk, j1 = (j0 + chunk < nwin) ? j0 + chunk : nwin;
+            const int chunk = (nwin + 63) / 64;
+            const int j0 = lane * chunk, j1 = (j0 + chunk < nwin) ? j0 + chunk : nwin;
             double ls = 0.0;
-            for (int j = j0; j < j1; ++j) ls += (double)s_abs[j];
+            for (int j = j0; j < j1; ++j) ls += (double)__builtin_fabsf(W.win[j]);
             double incl = ls;
             #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-            if (lane == 63) s_wtot[wv] = incl;
-            __syncthreads();
+            total = __shfl(incl, 63);
             double run = incl - ls;
-            for (int w = 0; w < wv; ++w) run += s_wtot[w];
-            if (tid == 0) s_pre[0] = 0.0;
-            for (int j = j0; j < j1; ++j) { run += (double)s_abs[j]; s_pre[j + 1] = run; }
-            __syncthreads();
+            auto put = [&](int p, double v) {                       // p = number of elements summed
+                const int ua = p - lo_a, ub = p - lo_b;
+                if (ua >= 0 && ua < nshift) W.a.pre[0][ua] = v;
+                if (ub >= 0 && ub < nshift) W.a.pre[1][ub] = v;
+            };
+            fence();                                                 // (the matched-filter inputs in region A are dead)
+            if (lane == 0) put(0, 0.0);
+            for (int j = j0; j < j1; ++j) { run += (double)__builtin_fabsf(W.win[j]); put(j + 1, run); }
         }
-        const int nshift = 2 * max_shift + 1;
-        const bool finite_all = s_pre[nwin] < 1.0e37;                // float32 sums cannot overflow below this
+        fence();
+        const bool finite_all = total < 1.0e37;                      // float32 sums cannot overflow below this
         double a1 = -1.0, a2 = -1.0;                                 // two largest exact-sum scores (with multiplicity)
-        for (int u = tid; u < nshift; u += LLR_THREADS) {
+        for (int u = lane; u < nshift; u += 64) {
             const int i0 = base + (u - max_shift);
             double A = -1.0;
-            if (i0 >= 0 && i0 + n <= nwin) A = (s_pre[i0 + n] - s_pre[i0 + guard]) / (double)(n - guard);
-            s_A[u] = A;
+            if (i0 >= 0 && i0 + n <= nwin) A = (W.a.pre[1][u] - W.a.pre[0][u]) / (double)(n - guard);
+            W.b.sh.A[u] = A;
             if (A > a1) { a2 = a1; a1 = A; } else if (A > a2) a2 = A;
         }
         #pragma unroll
@@ -396,103 +396,65 @@ __global__ __launch_bounds__(LLR_THREADS) void es_llr_kernel(const double* __res
             const double m2 = a2 > o2 ? a2 : o2;
             a1 = hi; a2 = lo > m2 ? lo : m2;
         }
-        if (lane == 0) { s_top[wv][0] = a1; s_top[wv][1] = a2; }
-        __syncthreads();
-        a1 = -1.0; a2 = -1.0;
-        #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            #pragma unroll
-            for (int e = 0; e < 2; ++e) { const double A = s_top[w][e]; if (A > a1) { a2 = a1; a1 = A; } else if (A > a2) a2 = A; }
-        }
-        // A(s) (1 + R) >= A2 (1 - R); with fewer than two valid shifts (a2 < 0) or non-finite data everything stays
-        // (scores down in the float32 subnormal range lose the relative bound: no screening there either)
+        fence();
         const double tau = (finite_all && a2 >= 1.0e-30) ? a2 * (1.0 - SCREEN_R) : -2.0;
         int ncand = 0;
-        for (int u0 = 0; u0 < nshift; u0 += LLR_THREADS) {           // ordered compaction, ascending shift
-            const int u = u0 + tid;
-            const bool isc = (u < nshift) && (s_A[u] >= 0.0) && (s_A[u] * (1.0 + SCREEN_R) >= tau);
+        for (int u0 = 0; u0 < nshift; u0 += 64) {                    // ordered compaction, ascending shift
+            const int u = u0 + lane;
+            const bool isc = (u < nshift) && (W.b.sh.A[u] >= 0.0) && (W.b.sh.A[u] * (1.0 + SCREEN_R) >= tau);
             const unsigned long long mb = __ballot(isc);
-            if (lane == 0) s_wcnt[wv] = __popcll(mb);
-            __syncthreads();
-            int off = ncand;
-            for (int w = 0; w < wv; ++w) off += s_wcnt[w];
             const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
-            if (isc) s_cand[off + below] = u - max_shift;
-            ncand += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-            __syncthreads();
+            if (isc) W.b.sh.cand[ncand + below] = u - max_shift;
+            ncand += __popcll(mb);
         }
-        float my_best = -1.0f, my_second = -1.0f; int my_s = 0;
-        for (int ci = wv; ci < ncand; ci += 4) {                     // ascending within a wave
-            const int s = s_cand[ci];
-            const int i0 = base + s;
-            const float sum = wave_pairwise_sum_nonneg(geo, lane, s_abs + i0 + guard);
-            const float score = sum / cnt_f;
-            if (score > my_best) { my_second = my_best; my_best = score; my_s = s; }
-            else if (score > my_second) my_second = score;
-        }
-        if (lane == 0) { s_score[wv][0] = my_best; s_score[wv][1] = my_second; s_shift[wv] = my_s; }
-        __syncthreads();
-        // first maximum in ascending-shift order wins (strict > in the reference)
+        fence();
         float best = -1.0f, second = -1.0f; int best_s = 0;
-        #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float b0 = s_score[w][0], b1 = s_score[w][1]; const int sh = s_shift[w];
-            if (b0 > best || (b0 == best && sh < best_s)) {
-                if (best > second) second = best;
-                best = b0; best_s = sh;
-            } else if (b0 > second) second = b0;
-            if (b1 > second) second = b1;
+        for (int ci = 0; ci < ncand; ++ci) {                         // ascending shift: the first maximum wins (strict > in the reference)
+            const int s = W.b.sh.cand[ci];
+            const float sum = wave_pairwise_sum_nonneg_abs(geo, lane, W.win + base + s + guard);
+            const float score = sum / cnt_f;
+            if (score > best) { second = best; best = score; best_s = s; }
+            else if (score > second) second = score;
         }
 
         // ---- despread at the chosen shift (:382-385)
         const int a0 = base + best_s;
-        for (int i = tid; i < n; i += LLR_THREADS) s_d[i] = s_win[a0 + i] * s_pn[i];
-        __syncthreads();
+        fence();
+        for (int i = lane; i < n; i += 64) W.a.d[i] = W.win[a0 + i] * pn_sym(i);
+        fence();
 
-        // ---- robust statistics on the tail (:395-404)
+        // ---- robust statistics on the tail (:395-404): median and MAD (exact selects), then mean and variance (NumPy order)
         const int toff = (n > guard + 8) ? guard : 0;
         const int nt = n - toff;
-        const float* tail = s_d + toff;
-        // wave 0: median and MAD (barrier-free selects); wave 1, at the same time: mean and variance
-        if (wv == 0) {
-            const float medv = wave_median_hist_f32(s_hist4, nt, lane, [&](int i) { return tail[i]; });
-            const float madv = wave_median_hist_f32(s_hist4, nt, lane, [&](int i) { return __builtin_fabsf(tail[i] - medv); });
-            if (lane == 0) s_stats[2] = madv;
-        } else if (wv == 1) {
-            PwPlan tp; pw_plan_build(tp, nt);
-            const float mu = wave_pairwise_sum(tp, lane, [&](int i) { return tail[i]; }) / (float)nt;
-            const float var = wave_pairwise_sum(tp, lane, [&](int i) { const float c = tail[i] - mu; return c * c; }) / (float)nt;
-            if (lane == 0) { s_stats[0] = mu; s_stats[3] = var; }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            const float madv = s_stats[2], var = s_stats[3];
-            const double mad = (double)madv + 1e-12;
-            const double sigma_mad = 1.4826 * mad;
-            const double sigma_std = (double)__builtin_sqrtf(var) + 1e-12;
-            double sigma = sigma_mad > sigma_std ? sigma_mad : sigma_std;
-            if (0.1 > sigma) sigma = 0.1;
-            double scale = 2.0 / (sigma * sigma);
-            if (scale < 0.5) scale = 0.5;
-            if (scale > 30.0) scale = 30.0;
-            s_stats[1] = (float)scale;
-        }
-        __syncthreads();
-        const float mu = s_stats[0], scale32 = s_stats[1];
-        for (int i = tid; i < NPAY; i += LLR_THREADS) {
+        const float* tail = W.a.d + toff;
+        const float medv = wave_median_hist_f32(W.b.hist, nt, lane, [&](int i) { return tail[i]; });
+        const float madv = wave_median_hist_f32(W.b.hist, nt, lane, [&](int i) { return __builtin_fabsf(tail[i] - medv); });
+        PwPlan tp; pw_plan_build(tp, nt);
+        const float mu = wave_pairwise_sum(tp, lane, [&](int i) { return tail[i]; }) / (float)nt;
+        const float var = wave_pairwise_sum(tp, lane, [&](int i) { const float c = tail[i] - mu; return c * c; }) / (float)nt;
+        const double mad = (double)madv + 1e-12;
+        const double sigma_mad = 1.4826 * mad;
+        const double sigma_std = (double)__builtin_sqrtf(var) + 1e-12;
+        double sigma = sigma_mad > sigma_std ? sigma_mad : sigma_std;
+        if (0.1 > sigma) sigma = 0.1;
+        double scale = 2.0 / (sigma * sigma);
+        if (scale < 0.5) scale = 0.5;
+        if (scale > 30.0) scale = 30.0;
+        const float scale32 = (float)scale;
+        for (int i = lane; i < NPAY; i += 64) {
             float v = 0.0f;
             if (i < n) {
-                v = (s_d[i] - mu) * scale32;                          // :397,405
+                v = (W.a.d[i] - mu) * scale32;                        // :397,405
                 if (v < -12.0f) v = -12.0f;
                 if (v > 12.0f) v = 12.0f;
             }
             out[i] = v;
         }
-        if (tid == 0) {
+        if (lane == 0) {
             if (best_s_out) best_s_out[rec] = best_s;
             if (score_out) { score_out[2 * rec] = best; score_out[2 * rec + 1] = second; }
         }
-        __syncthreads();
+        fence();
     }
 }
 
@@ -622,10 +584,10 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
                   const uint8_t* band, const uint8_t* pn, int variant, float* llr, int32_t* best_s,
                   float* score, hipStream_t st)
 {
-    long long blocks = B;
-    const long long cap = (long long)ctx->num_cu * 12;
+    long long blocks = (B + LW_WAVES - 1) / LW_WAVES;
+    const long long cap = (long long)ctx->num_cu * 64 / LW_WAVES;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(es_llr_kernel, dim3((unsigned)blocks), dim3(LLR_THREADS), 0, st, y, (long long)B, T,
+    hipLaunchKernelGGL(es_llr_wave_kernel, dim3((unsigned)blocks), dim3(64 * LW_WAVES), 0, st, y, (long long)B, T,
                        start, band, pn, variant, ctx->d_tables, llr, best_s, score);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
