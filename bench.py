@@ -68,7 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frame records per GPU per step (C2 = 1024)")
     ap.add_argument("--list-size", type=int, default=8)
-    ap.add_argument("--legs", default="auto", help="comma list of c3,c4,c5 (auto: all at N = 1, c4 at N > 1; none: headline only)")
+    ap.add_argument("--legs", default="auto", help="comma list of c3,c4,c5 (auto: all at N = 1, c3 + c4 at N > 1; none: headline only)")
     ap.add_argument("--c3-windows", type=int, default=65536)
     ap.add_argument("--c3-steps", type=int, default=8)
     ap.add_argument("--c4-frames", type=int, default=1 << 20, help="total frames of the strong-scaling leg (all ranks together)")
@@ -203,7 +203,7 @@ def run_rank(a) -> None:
     from echoseal_amd.engine import DecodePipeline, RxEngine
     from echoseal_amd import workloads as WL
 
-    legs = {"auto": ["c3", "c4", "c5"] if world == 1 else ["c4"], "none": []}.get(a.legs, a.legs.split(","))
+    legs = {"auto": ["c3", "c4", "c5"] if world == 1 else ["c3", "c4"], "none": []}.get(a.legs, a.legs.split(","))
     L = a.list_size
     eng = RxEngine(local, list_size_max=max(16, L))
 
@@ -257,7 +257,7 @@ def run_rank(a) -> None:
 
     # ============================================================ leg c3 (one GPU): 65 536 jittered / noisy windows
     roof_c3 = roof_fused = None
-    if "c3" in legs and world == 1:
+    if "c3" in legs:                                       # (at N > 1 every rank runs the same windows: the leg reports rank 0's rate)
         Bw = a.c3_windows
         parts, pays = [], []
         for c0 in range(0, Bw, 16384):
@@ -299,13 +299,13 @@ def run_rank(a) -> None:
             for k in range(steps):
                 res3 = c3_step(k, fused=fused)
             barrier()
-            dt3 = time.perf_counter() - t0
+            dt3 = max_over_ranks(time.perf_counter() - t0)
             x_ms = float(np.mean([s.elapsed_time(e) for s, e in ev3[:steps]]))
             names = ("bpf", "sync_fused" if fused else "xcorr32", "(in sync_fused)" if fused else "pick_exact", "llr", "scl", "select")
             stage_ms = {n: float(np.mean([st[i].elapsed_time(st[i + 1]) for st in stage[:steps]])) for i, n in enumerate(names)}
             return dt3, x_ms, stage_ms, res3
 
-        wl3 = (f"C3: {Bw} windows of 2048 float32 samples, one frame each (ctr = i, resampled by U[0.95,1.05] with linear interpolation, uniform "
+        wl3 = (f"C3: {Bw} windows of 2048 float32 samples per GPU, one frame each (ctr = i, resampled by U[0.95,1.05] with linear interpolation, uniform "
                f"offset, AWGN at -15 dB SNR), generated on the device; band-pass -> float32 NCC screen + exact median/MAD threshold + NMS/top-5 "
                f"-> _llr at the detected peak -> SCL-{L} -> selection")
         _dt_seq, xf_ms, stage_ms, (pk, npk, flags, payload, ok) = c3_run(True, 2)          # sequential pass: stage breakdown, reference results
@@ -322,7 +322,7 @@ def run_rank(a) -> None:
         for k in range(a.c3_steps):
             sy3, scl3 = c3_lane_step()
         barrier()
-        dt3 = time.perf_counter() - t0
+        dt3 = max_over_ranks(time.perf_counter() - t0)
         same_lane = bool(torch.equal(sy3.peaks, pk) and torch.equal(sy3.npeaks, npk) and torch.equal(scl3.selected[0], payload) and torch.equal(scl3.selected[1], ok))
         del pipe3, sy3, scl3
         found = int(((pk[:, :5] - off[:, None]).abs() <= 2).any(dim=1).sum().item())
@@ -334,7 +334,7 @@ def run_rank(a) -> None:
                               "float64 re-evaluations, not by HBM -- it exists to take 2 x 7 944 B per window of screen traffic and two launches away",
                       "where": f"HIP events around the launch inside the timed c3 leg ({a.c3_steps} steps)"}
         out_legs["c3"] = {"workload": wl3 + f" [sync: es_sync_fused_batch; steps alternate between {a.big_lanes} pipeline lanes]",
-                          "value": Bw * a.c3_steps / dt3, "unit": "windows/s", "steps": a.c3_steps, "ms_per_step": 1e3 * dt3 / a.c3_steps,
+                          "value": world * Bw * a.c3_steps / dt3, "unit": "windows/s", "scaling": "weak", "steps": a.c3_steps, "ms_per_step": 1e3 * dt3 / a.c3_steps,
                           "stage_ms_one_step_alone": stage_ms, "results_identical_to_the_sequential_pass": same_lane,
                           "records_settled_by_the_exact_float64_row": int((flags != 0).sum().item()),
                           "windows_with_a_top5_peak_within_2_samples_of_the_true_offset": found,
@@ -352,7 +352,7 @@ def run_rank(a) -> None:
                    "launch_ms": x_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_WINDOW * Bw,
                    "where": f"HIP events around the launch inside the timed c3_unfused leg ({nu} steps)"}
         out_legs["c3_unfused"] = {"workload": wl3 + " [sync: es_xcorr32_batch + es_pick_exact_batch, screen through HBM]",
-                                  "value": Bw * nu / dtu, "unit": "windows/s", "steps": nu, "ms_per_step": 1e3 * dtu / nu, "stage_ms": stage_u,
+                                  "value": world * Bw * nu / dtu, "unit": "windows/s", "scaling": "weak", "steps": nu, "ms_per_step": 1e3 * dtu / nu, "stage_ms": stage_u,
                                   "results_identical_to_c3": same}
         del pk2, npk2, flags2, payload2, ok2
         del win, off, pn3, band3, pk, npk, flags, payload, ok
