@@ -5,7 +5,7 @@
 set -e
 R=$(pwd)
 OUT=$R/gpurun_out/r2/pmc
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $OUT/ub_rowcopy $R/tools/ub/ub_rowcopy.hip
 for c in FETCH_SIZE WRITE_SIZE; do

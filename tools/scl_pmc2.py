@@ -12,6 +12,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 base = torch.from_numpy(np.clip(rng.normal(0, 3, (4096, 1024)), -12, 12).astype(np.float32)).to(eng.device)
 llr = base.repeat(-(-B // 4096), 1)[:B].contiguous()
 eng.set_option("scl_multi", 1)
-for _ in range(2):
-    eng.scl(llr, list_size=8, skip_if_hard_ok=False)
+for lanes in (4, 2):                     # 16 paths x 4 lanes per wave (the pipeline's kernel), 32 paths x 2 lanes (large batches)
+    eng.set_option("scl_lanes", lanes)
+    for _ in range(2):
+        eng.scl(llr, list_size=8, skip_if_hard_ok=False)
 torch.cuda.synchronize()

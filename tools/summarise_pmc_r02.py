@@ -42,23 +42,26 @@ for key, part, bytes_alg in (("c3_launch", "<17, 2048, false>", B * (4 * 2048 + 
 out["c3_launch_fused"]["note"] = "reads also cover the float64 samples of the exact re-evaluations (~80 doubles per evaluated lag) and the tables"
 json.dump(out, open(os.path.join(DST, "r02_xcorr32_pmc_traffic.json"), "w"), indent=1)
 
-# ---- list decoder
+# ---- list decoder (both mappings of the multi-frame kernel)
 sa = counters("scl_a", "es_scl_multi_kernel"); sb = counters("scl_b", "es_scl_multi_kernel")
-g = lambda d, c: pick(d, "es_scl_multi_kernel", c)
-valu, act, wave_cyc = g(sa, "SQ_INSTS_VALU"), g(sa, "SQ_ACTIVE_INST_VALU"), g(sa, "SQ_WAVE_CYCLES")
-gui = g(sb, "GRBM_GUI_ACTIVE") / 8.0
 scl = {"source": "rocprofv3 --pmc (two passes of 8 SQ/GRBM counters, counters only) -- python3 tools/scl_pmc2.py '' 65536; MI355X, round 2; "
-                 "SQ_* cycle counters are in quad-cycles, GRBM_GUI_ACTIVE sums the 8 XCDs",
-       "es_scl_multi_kernel<8>  B=65536 (three waves per SIMD, two frames per wave)": {
-           "SQ_WAVES": g(sa, "SQ_WAVES"), "GRBM_GUI_ACTIVE": g(sb, "GRBM_GUI_ACTIVE"), "SQ_WAVE_CYCLES": wave_cyc, "SQ_INSTS_VALU": valu,
-           "SQ_ACTIVE_INST_VALU": act, "SQ_WAIT_INST_ANY": g(sa, "SQ_WAIT_INST_ANY"), "SQ_WAIT_ANY": g(sa, "SQ_WAIT_ANY"),
-           "SQ_INSTS_SALU": g(sb, "SQ_INSTS_SALU"), "SQ_INSTS_LDS": g(sb, "SQ_INSTS_LDS"), "SQ_INSTS_VMEM_RD": g(sb, "SQ_INSTS_VMEM_RD"),
-           "SQ_INSTS_VMEM_WR": g(sb, "SQ_INSTS_VMEM_WR"), "SQ_LDS_BANK_CONFLICT": g(sb, "SQ_LDS_BANK_CONFLICT"),
-           "per_frame": {"valu_instructions": round(valu / B), "salu_instructions": round(g(sb, "SQ_INSTS_SALU") / B), "lds_instructions": round(g(sb, "SQ_INSTS_LDS") / B)},
-           "cycles_per_valu_instruction": 4.0 * act / valu,
-           "valu_active_fraction_per_simd": 4.0 * act / 1024.0 / gui,
-           "reading": "every vector instruction holds its SIMD's vector unit for ~4 cycles (FP64 and 32-bit alike in this mix), so the issue peak is one "
-                      "wave-instruction per 4 cycles and SIMD; the unit is active ~3/4 of the kernel's time with three waves per SIMD"}}
+                 "SQ_* cycle counters are in quad-cycles, GRBM_GUI_ACTIVE sums the 8 XCDs"}
+for tag, part, what in (("es_scl_multi_kernel<8>  B=65536, 16 paths x 4 lanes per wave (the mapping of the pipelined headline)", "<8, 4>", "two frames per wave"),
+                        ("es_scl_multi_kernel<8,2 lanes>  B=65536, 32 paths x 2 lanes per wave (batches of tens of thousands of frames)", "<8, 2>", "four frames per wave")):
+    g = lambda d, c: pick(d, part, c)
+    valu, act = g(sa, "SQ_INSTS_VALU"), g(sa, "SQ_ACTIVE_INST_VALU")
+    gui = g(sb, "GRBM_GUI_ACTIVE") / 8.0
+    scl[tag] = {
+        "SQ_WAVES": g(sa, "SQ_WAVES"), "GRBM_GUI_ACTIVE": g(sb, "GRBM_GUI_ACTIVE"), "SQ_WAVE_CYCLES": g(sa, "SQ_WAVE_CYCLES"), "SQ_INSTS_VALU": valu,
+        "SQ_ACTIVE_INST_VALU": act, "SQ_WAIT_INST_ANY": g(sa, "SQ_WAIT_INST_ANY"), "SQ_WAIT_ANY": g(sa, "SQ_WAIT_ANY"),
+        "SQ_INSTS_SALU": g(sb, "SQ_INSTS_SALU"), "SQ_INSTS_LDS": g(sb, "SQ_INSTS_LDS"), "SQ_INSTS_VMEM_RD": g(sb, "SQ_INSTS_VMEM_RD"),
+        "SQ_INSTS_VMEM_WR": g(sb, "SQ_INSTS_VMEM_WR"), "SQ_LDS_BANK_CONFLICT": g(sb, "SQ_LDS_BANK_CONFLICT"),
+        "per_frame": {"valu_instructions": round(valu / B), "salu_instructions": round(g(sb, "SQ_INSTS_SALU") / B), "lds_instructions": round(g(sb, "SQ_INSTS_LDS") / B)},
+        "cycles_per_valu_instruction": 4.0 * act / valu,
+        "valu_active_fraction_per_simd": 4.0 * act / 1024.0 / gui,
+        "kernel_ms_at_2.35GHz": gui / 2.35e6,
+        "reading": f"three waves per SIMD, {what}; every vector instruction holds its SIMD's vector unit for ~4 cycles (FP64 and 32-bit alike in "
+                   "this mix), so the issue peak is one wave-instruction per 4 cycles and SIMD"}
 json.dump(scl, open(os.path.join(DST, "r02_scl_pmc.json"), "w"), indent=1)
 
 for f in glob.glob(os.path.join(SRC, "bench_stats", "**", "*kernel_stats.csv"), recursive=True):
