@@ -21,13 +21,14 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     q = rng.choice([-12.0, -6.0, -3.0, 0.0, 3.0, 6.0, 12.0], size=(B, 1024), p=[.1, .15, .2, .1, .2, .15, .1]).astype(np.float32)
     q[: B // 2] += rng.choice([0.0, 0.5], size=(B // 2, 1024)).astype(np.float32)
     x = torch.from_numpy(q).to(dev)
-    for L in (1, 2, 4, 8, 16):
+    for L in (1, 2, 4, 8, 16, int(rng.choice([3, 5, 6, 7, 11, 13]))):
         eng.set_option("scl_multi", 0); a = eng.scl(x, list_size=L, skip_if_hard_ok=False)
-        eng.set_option("scl_multi", 1); b = eng.scl(x, list_size=L, skip_if_hard_ok=False)
-        eng.set_option("scl_multi", -1)
-        for nm in ("hard_info", "hard_ok", "ncand", "cand_info", "cand_metric", "cand_ok"):
-            if not torch.equal(getattr(a, nm), getattr(b, nm)):
-                bad += 1; print("SCL kernels differ", seed, L, nm)
+        for lanes in (4, 2):                         # the two mappings of the multi-frame kernel against the one-frame kernel
+            eng.set_option("scl_multi", 1); eng.set_option("scl_lanes", lanes); b = eng.scl(x, list_size=L, skip_if_hard_ok=False)
+            eng.set_option("scl_multi", -1); eng.set_option("scl_lanes", 0)
+            for nm in ("hard_info", "hard_ok", "ncand", "cand_info", "cand_metric", "cand_ok"):
+                if not torch.equal(getattr(a, nm), getattr(b, nm)):
+                    bad += 1; print("SCL kernels differ", seed, L, lanes, nm)
         for i in rng.integers(0, B, 3):
             nn, ci, cm, cc = orc.scl_list(q[i].astype(np.float64), L)
             if not (np.array_equal(np.packbits(ci[:nn], axis=1), a.cand_info[i, :nn].cpu().numpy()) and np.array_equal(cm[:nn], a.cand_metric[i, :nn].cpu().numpy())):
@@ -50,10 +51,12 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
             off = int(rng.integers(0, T - 1215 + 1))
             r[i, off:off + 1215] += (amp * FR[i % len(FR)]).astype(np.float32)
     f = torch.from_numpy(r).to(dev); bb = torch.from_numpy(band).to(dev)
-    ref = eng.sync(f, bb, keep_corr=False); fast = eng.sync_fast(f, bb)
+    ref = eng.sync(f, bb, keep_corr=False)
     k = (ref.npeaks & 0xFFFF).clamp(max=32); mask = torch.arange(32, device=dev)[None, :] < k[:, None]
-    if not (torch.equal(ref.thr, fast.thr) and torch.equal(ref.npeaks, fast.npeaks) and torch.equal(ref.peaks[mask], fast.peaks[mask])):
-        bad += 1; print("sync fast vs float64 differ", seed, T)
+    for fused in (True, False):                      # one kernel with the row in LDS / screen through HBM
+        fast = eng.sync_fast(f, bb, fused=fused)
+        if not (torch.equal(ref.thr, fast.thr) and torch.equal(ref.npeaks, fast.npeaks) and torch.equal(ref.peaks[mask], fast.peaks[mask])):
+            bad += 1; print("sync fast vs float64 differ", seed, T, "fused" if fused else "unfused")
     # ---- LLR with the screened shift search vs oracle
     m = 24
     yy = rng.normal(0, rng.choice([1e-3, 0.1, 3.0]), (m, 1215))
