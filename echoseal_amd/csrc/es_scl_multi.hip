@@ -175,6 +175,7 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
             wave_fence_lds();
             if (ok && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
                 if (lane == 0) a.ncand[ff] = 0;
+                #pragma unroll 1
                 for (int k = lane; k < a.lsz * ES_INFO_BYTES; k += 64) a.cand_info[ff * a.lsz * ES_INFO_BYTES + k] = 0;
                 if (lane < a.lsz) { a.cand_metric[ff * a.lsz + lane] = 0.0; a.cand_ok[ff * a.lsz + lane] = 0; }
             } else active_mask |= 1u << fi;
@@ -544,7 +545,8 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
         }
         wave_fence_lds();
         if (pl < cnt && f_store) {
-            for (int k = q; k < ES_INFO_BYTES; k += P)
+            #pragma unroll 1
+            for (int k = q; k < ES_INFO_BYTES; k += P)                       // (unrolled, its 28 index registers stay live through the whole bit loop)
                 a.cand_info[(f * a.lsz + rank) * ES_INFO_BYTES + k] = W.outb[path][k];
         }
         if (q == 0 && pl == 0 && f_store) a.ncand[f] = cnt;
