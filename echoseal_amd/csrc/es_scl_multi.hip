@@ -45,6 +45,11 @@ constexpr int MWPB = 4;                            // waves per block
 #ifndef ES_MULTI_ILP
 #define ES_MULTI_ILP 1                             // independent f evaluations in flight per lane in the slot-storage loops
 #endif
+#ifndef ES_MULTI_INTERLEAVE
+#define ES_MULTI_INTERLEAVE 0                      /* slab regions interleaved over the paths of a wave (coalesced 512-byte wave accesses): measured SLOWER
+                                                      (1.63 M against 2.03 M frames/s with four lanes per path) -- the index arithmetic per access costs more
+                                                      vector instructions than the fewer cache lines save, and a path's own row gives each lane a second hit per line */
+#endif
 #ifndef ES_MULTI_PREFETCH
 #define ES_MULTI_PREFETCH 0                         /* next pair of parents loaded ahead: measured slower (1.51 M against 1.75 M frames/s) */
 #endif
@@ -122,6 +127,15 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
     const long long wave_id = (long long)blockIdx.x * MWPB + wv;
     double* const scr = a.scratch + ((long long)slot * MWPB + wv) * (long long)mslab_doubles<PP>();
     uint32_t* const tbw_g = reinterpret_cast<uint32_t*>(scr + MNP * MGSLOT);          // P = 2: trace-back windows [MWIN][MNP]
+#if ES_MULTI_INTERLEAVE
+    // Slab layout of a wave: per tree depth a region of MNP x S doubles, INTERLEAVED over the paths in chunks of P elements:
+    // element j of slot s at ((j / P) * MNP + s) * P + j % P.  The lanes of a path walk j = q, q + P, ..., so one wave
+    // instruction touches MNP chunks of P doubles that are CONTIGUOUS (512 bytes; a sort only permutes which chunk a path
+    // reads) instead of MNP separate 32- or 16-byte pieces of as many cache lines.
+    auto gaddr = [&](int off, int slot, int j) -> double* { return scr + (long long)MNP * off + (((j >> LGP) * MNP + slot) << LGP) + (j & (P - 1)); };
+#else
+    auto gaddr = [&](int off, int slot, int j) -> double* { return scr + slot * MGSLOT + off + j; };
+#endif
     const uint64_t* const tab = s_exp;
     const long long n_groups = (a.B + FR - 1) / FR;
 
@@ -229,18 +243,16 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
                 const int own = first ? fp0 : path;
                 const int j0 = first ? (lane % FL) : q;
                 const int jst = first ? FL : P;
-                const double* par_g = scr + ps * MGSLOT + (N - 4 * S);         // depth d-1 in scratch: 0, 512, 768, 896
-                const double* par_l = &W.alphaS[ps][2 * S];
-                double* dst_g = scr + own * MGSLOT + (N - 2 * S);
+                const double* par_l = &W.alphaS[ps][2 * S];                    // (depth d-1 in the slab: region offset N - 4S; depth d: N - 2S)
                 double* dst_l = &W.alphaS[own][S];
                 auto load_pair = [&](int j, double& pa, double& pb) {
                     if (d == 1) {
                         if (a.is_f64) { pa = llr64[j]; pb = llr64[j + S]; }
                         else { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }
-                    } else if (d - 1 <= MGDEPTH) { pa = par_g[j]; pb = par_g[j + S]; }
+                    } else if (d - 1 <= MGDEPTH) { pa = *gaddr(N - 4 * S, ps, j); pb = *gaddr(N - 4 * S, ps, j + S); }
                     else { pa = par_l[j]; pb = par_l[j + S]; }
                 };
-                auto store_out = [&](int j, double v) { if (d <= MGDEPTH) dst_g[j] = v; else dst_l[j] = v; };
+                auto store_out = [&](int j, double v) { if (d <= MGDEPTH) *gaddr(N - 2 * S, own, j) = v; else dst_l[j] = v; };
                 if (is_g) {
                     for (int j = q; j < S; j += P) {
                         double pa, pb; load_pair(j, pa, pb);
@@ -325,11 +337,10 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
                 const int S = 1 << blk;
                 if (S > P) {
                     const int dn = NLEV - blk;                        // the node's depth: 4 (scratch) .. 7 (LDS)
-                    double* const Xg = scr + path * MGSLOT + (N - 2 * S);
                     double* const Xl = &W.alphaS[path][S];
                     const bool in_g = dn <= MGDEPTH;
-                    auto ld = [&](int e) { return in_g ? Xg[e] : Xl[e]; };
-                    auto st = [&](int e, double v) { if (in_g) Xg[e] = v; else Xl[e] = v; };
+                    auto ld = [&](int e) { return in_g ? *gaddr(N - 2 * S, path, e) : Xl[e]; };
+                    auto st = [&](int e, double v) { if (in_g) *gaddr(N - 2 * S, path, e) = v; else Xl[e] = v; };
                     for (int h = S >> 1; h >= P; h >>= 1) {           // nodes of 2h values -> children of h values
                         const int lh = 31 - __builtin_clz((unsigned)h);
                         int idx = q;
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
                 const int nleaf = (S < P) ? S : P;
                 for (int sb = 0; sb < nsub; ++sb) {
                     double x = ar[0];
-                    if (S > P) x = (NLEV - blk <= MGDEPTH) ? scr[path * MGSLOT + (N - 2 * S) + sb * P + q] : W.alphaS[path][S + sb * P + q];
+                    if (S > P) x = (NLEV - blk <= MGDEPTH) ? *gaddr(N - 2 * S, path, sb * P + q) : W.alphaS[path][S + sb * P + q];
                     #pragma unroll
                     for (int k = 1; k <= LGP; ++k) if (k == k0) x = ar[k];
                     double L2last = 0.0;
