@@ -45,11 +45,6 @@ constexpr int MWPB = 4;                            // waves per block
 #ifndef ES_MULTI_ILP
 #define ES_MULTI_ILP 1                             // independent f evaluations in flight per lane in the slot-storage loops
 #endif
-#ifndef ES_MULTI_INTERLEAVE
-#define ES_MULTI_INTERLEAVE 0                      /* slab regions interleaved over the paths of a wave (coalesced 512-byte wave accesses): measured SLOWER
-                                                      (1.63 M against 2.03 M frames/s with four lanes per path) -- the index arithmetic per access costs more
-                                                      vector instructions than the fewer cache lines save, and a path's own row gives each lane a second hit per line */
-#endif
 #ifndef ES_MULTI_PREFETCH
 #define ES_MULTI_PREFETCH 0                         /* next pair of parents loaded ahead: measured slower (1.51 M against 1.75 M frames/s) */
 #endif
@@ -127,15 +122,11 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
     const long long wave_id = (long long)blockIdx.x * MWPB + wv;
     double* const scr = a.scratch + ((long long)slot * MWPB + wv) * (long long)mslab_doubles<PP>();
     uint32_t* const tbw_g = reinterpret_cast<uint32_t*>(scr + MNP * MGSLOT);          // P = 2: trace-back windows [MWIN][MNP]
-#if ES_MULTI_INTERLEAVE
-    // Slab layout of a wave: per tree depth a region of MNP x S doubles, INTERLEAVED over the paths in chunks of P elements:
-    // element j of slot s at ((j / P) * MNP + s) * P + j % P.  The lanes of a path walk j = q, q + P, ..., so one wave
-    // instruction touches MNP chunks of P doubles that are CONTIGUOUS (512 bytes; a sort only permutes which chunk a path
-    // reads) instead of MNP separate 32- or 16-byte pieces of as many cache lines.
-    auto gaddr = [&](int off, int slot, int j) -> double* { return scr + (long long)MNP * off + (((j >> LGP) * MNP + slot) << LGP) + (j & (P - 1)); };
-#else
+    // Slab layout of a wave: one row of MGSLOT doubles per path slot, depth d at offset N - 2 (N >> d).  (An interleaved layout
+    // -- element j of slot s at ((j / P) * MNP + s) * P + j % P, so that a wave instruction touches 512 contiguous bytes --
+    // was measured SLOWER, 1.59 M against 2.02 M frames/s with four lanes per path: with a row per path every lane gets a
+    // second hit on each cache line, and the kernel is bound by vector issue, not by the memory pipeline.)
     auto gaddr = [&](int off, int slot, int j) -> double* { return scr + slot * MGSLOT + off + j; };
-#endif
     const uint64_t* const tab = s_exp;
     const long long n_groups = (a.B + FR - 1) / FR;
 
