@@ -451,16 +451,25 @@ def test_sync_fast_large_batch_property(engine):
     assert torch.equal(ref.peaks[mask], fast.peaks[mask])
 
 
-def test_decode_pipeline_equals_decode_batch(engine):
-    """The two-deep streaming pipeline (front end of batch k+1 beside SCL of batch k) returns, for every
-    batch, exactly what decode_batch returns for it -- including when different batches are in flight."""
+@pytest.mark.parametrize("mode", ["front+decoders", "lanes", "lanes, several frames per wave"])
+def test_decode_pipeline_equals_decode_batch(engine, mode):
+    """The streaming pipeline returns, for every batch, exactly what decode_batch returns for it -- including when
+    different batches are in flight: the round-1 arrangement (front-end stream + two list-decoder streams), the whole-chain
+    lanes that bench.py runs, and those with the multi-frame list decoder forced (its launches share nothing but the GPU)."""
     from echoseal_amd.engine import DecodePipeline
-    pipe = DecodePipeline(engine, list_size=8)
-    batches = [_workload(256, noise=n, seed=11 + k, ctr0=1000 * k) for k, n in enumerate((0.0, 0.05, 0.2, 0.0, 0.4))]
+    pipe = DecodePipeline(engine, list_size=8) if mode == "front+decoders" else DecodePipeline(engine, list_size=8, lanes=3)
+    if mode.endswith("per wave"):
+        for e in pipe.scl_engs:
+            e.set_option("scl_multi", 1)
+    batches = [_workload(256, noise=n, seed=11 + k, ctr0=1000 * k) for k, n in enumerate((0.0, 0.05, 0.2, 0.0, 0.4, 0.1, 0.0))]
     dev = [_dev(engine, *w) for w in batches]
-    out = [pipe.submit(f, b, p) for f, b, p in dev]           # all five enqueued back to back
+    out = [pipe.submit(f, b, p, select=(mode != "front+decoders")) for f, b, p in dev]           # all enqueued back to back
     pipe.synchronize()
+    engine.set_option("scl_multi", -1)
     for (f, b, p), (sy, llr, scl, done) in zip(dev, out):
+        if mode != "front+decoders":
+            for u, v in zip(scl.selected, engine.select(scl)):
+                assert torch.equal(u, v)
         rs, rl, rc = engine.decode_batch(f, b, p, list_size=8)
         torch.cuda.synchronize()
         assert torch.equal(sy.thr, rs.thr) and torch.equal(sy.peaks, rs.peaks) and torch.equal(sy.npeaks, rs.npeaks)
