@@ -311,13 +311,16 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     int lp = 1; while (lp < list_size) lp <<= 1;              // the kernels are built for powers of two; any size runs on the next one
-    if (lp <= 16) {
+    if (lp <= 32) {
         // several frames per wave (es_scl_multi.hip) once the batch yields enough such waves (16/L frames each).  One
         // frame per wave wastes more lanes the shorter the list is, so the break-even moves down with L: measured
         // at L = 8 it is two waves per SIMD (B = 4 096), at L = 1 a quarter of a wave per SIMD.
         const long long waves = (B * lp + 15) / 16;
-        // (L = 16 runs on that kernel too when forced, but measures no faster than one frame per wave: auto leaves it alone)
-        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && lp <= 8 && waves >= (long long)ctx->num_cu * lp);
+        // L = 16 and 32 map to one frame per wave on either kernel (16 paths x 4 lanes, 32 x 2); the multi-frame kernel's smaller
+        // footprint (three waves per SIMD, non-persistent blocks) wins as soon as the batch exceeds one wave per SIMD:
+        // measured 2.1x at L = 16 and 4.1x at L = 32 for 16 384 frames, equal below 1 024 / 512 frames.
+        const bool fits = lp <= 8 ? waves >= (long long)ctx->num_cu * lp : B >= (lp == 16 ? 4LL : 2LL) * ctx->num_cu + (lp == 32);
+        const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && fits);
         if (multi)
             return es_launch_scl_multi(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                        cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
     constexpr int P = C::P, LGP = C::LGP, RD = C::RD, MNP = C::NP, MGDEPTH = C::GDEPTH, MGSLOT = C::GSLOT;
     constexpr int FR = MNP / L;                    // frames per wave
     constexpr int FL = 64 / FR;                    // lanes per frame
-    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16, "lists of at most 16 paths");
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || (L == 32 && PP == 2), "lists of at most 16 paths (32 with two lanes per path)");
     static_assert(PP == 2 || PP == 4, "two or four lanes per path");
     __shared__ __attribute__((aligned(16))) uint64_t s_exp[ES_EXP_TAB_WORDS];
     __shared__ uint16_t s_dpos[KINFO];
@@ -610,6 +610,7 @@ int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int 
         case 4: return two ? launch_multi<4, 2>(ctx, a, B, st) : launch_multi<4, 4>(ctx, a, B, st);
         case 8: return two ? launch_multi<8, 2>(ctx, a, B, st) : launch_multi<8, 4>(ctx, a, B, st);
         case 16: return two ? launch_multi<16, 2>(ctx, a, B, st) : launch_multi<16, 4>(ctx, a, B, st);
-        default: ctx->err = "the multi-frame list decoder serves list sizes up to 16"; return ES_EINVAL;
+        case 32: return launch_multi<32, 2>(ctx, a, B, st);          // one frame per wave, 32 paths x 2 lanes
+        default: ctx->err = "the multi-frame list decoder serves list sizes up to 32"; return ES_EINVAL;
     }
 }

@@ -1,68 +1,138 @@
 // es_scl_wide.hip -- SCL decoder for LARGE lists (L = 64, 128, 256), one workgroup per frame,
 // one LANE per path.  Same arithmetic and the same bookkeeping idea as es_scl.hip (per-depth slot
-// pointers instead of path copies, trace-back instead of per-path bit arrays, stable rank sort),
-// but with L > 32 a frame no longer fits one wavefront:
-//   * lane p owns path p and walks the elements of a tree node serially; the L paths advance in
-//     lock step with a workgroup barrier after every depth (a path may read its parent's slot,
-//     which another wave has just written);
-//   * the LLR tree of all paths lives in an L2/Infinity-Cache resident scratch slab laid out
-//     [element][slot] so that the lanes of a wave touch one contiguous row;
-//   * slot-pointer tables (one byte per depth and path), partial-sum bit blocks and the candidate
-//     metrics live in LDS; the tables are double-buffered and re-indexed by parent at each sort.
-// The detector's default list size is 256 (rtwm/detector.py:27); this kernel is what lets
-// WatermarkDetector(key).verify(...) run unchanged.  Values are bit-identical to the reference
-// list decoder for the same reason as in es_scl.hip (es_math.h).
-#include "es_internal.h"
-#include "es_math.h"
+// pointers instead of path copies, trace-back instead of per-path bit arrays, Python's stable sort
+// order), but with L > 32 a frame no longer fits one wavefront.  The detector's default list size is
+// 256 (rtwm/detector.py:27); this kernel is what lets WatermarkDetector(key).verify(...) run unchanged.
+//
+// Where things live (lane p owns path p and slot p of every slot-indexed store):
+//   * LLR tree depths 1..7 (512..8 values per path): an L2 / Infinity-Cache resident scratch slab laid out
+//     [element][slot], so the lanes of a wave touch one contiguous row; a lane walks a node's elements serially.
+//   * depths 8 and 9 (4 + 2 values): LDS, [element][slot]; depth 10 (the leaf LLR): a register.
+//   * slot pointers (which slot holds my data at depth d): one byte per depth packed in two 64-bit registers,
+//     partial-sum blocks of 1..16 bits in one 32-bit register (as in es_scl.hip), of 32..128 bits in LDS by
+//     slot, of 256 / 512 bits (read three times per frame) in the slab.
+//   * a sort moves registers only: every path publishes (pointers, small partial sums, trace-back window, the
+//     softplus pair of the even sibling) to LDS, and the survivor of rank r -- lane r -- reads its parent's.
+//   * trace-back by windows of 32 information bits (as in es_scl_multi.hip): a path carries the bits of the
+//     current window and the path it descended from at the window's start; a full window goes to the slab once.
+//
+// The sort is a bitonic network over the 2L candidates on (metric, candidate index) -- a strict total order, so
+// the result is Python's stable list.sort -- with two candidates per lane IN REGISTERS: partner lanes exchange
+// through DPP / ds_swizzle / ds_bpermute, only the stages whose partner sits in another wave (3 of 45 at L = 256)
+// go through LDS and a workgroup barrier.
+//
+// Barriers.  A path may read a slot that another wave wrote, but only one it inherited at a sort (whose barriers
+// order the write before the read); and a lane only ever writes its OWN slot.  What remains is write-after-read:
+// before a step that writes shared slots, every wave must have finished the reads of earlier steps -- one barrier,
+// and only when no sort has happened since those reads (`dirty`).  A depth-by-depth barrier is not needed: within a
+// step a path reads what it has itself just written.
+//
+// Values are bit-identical to the reference list decoder for the same reason as in es_scl.hip (es_math.h).
+#include "es_scl_common.h"
 
 namespace {
-
-constexpr int N = ES_POLAR_N;
-constexpr int NLEV = 10;
-constexpr int KINFO = ES_POLAR_K;
 
 struct WideArgs {
     const void* llr; int is_f64; long long B;
     es_frozen_mask frozen;
     const uint16_t* data_pos;
     const uint64_t* exp_tab;
-    double* alpha;        // [slots][1024][L]
-    uint16_t* tb;         // [slots][448][L]
+    double* alpha;            // [slots][1024][L]   (elements 8..1023 used: depth d at [1024 >> d, 2 * (1024 >> d)))
+    unsigned char* aux;       // [slots][ES_WIDE_AUX_PER_PATH * L]: trace-back windows, wide partial-sum blocks, fold scratch
     uint8_t* hard_info; uint8_t* hard_ok;
     uint8_t* cand_info; double* cand_metric; uint8_t* cand_ok; int32_t* ncand;
     int skip_if_hard_ok;
     int lsz;                                  // the caller's list size (<= L)
 };
 
-__device__ __forceinline__ uint8_t crc8_bytes_w(const uint8_t* b, int n)
-{
-    uint32_t reg = 0;
-    for (int i = 0; i < n; ++i) {
-        reg ^= b[i];
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
-    }
-    return (uint8_t)reg;
-}
+constexpr int MWIN_W = KINFO / 32;            // trace-back windows
+// aux slab per path: windows 14 x (4 + 2) B, partial-sum blocks of 256 / 512 bits 24 x 4 B, fold scratch 16 x 4 B
+constexpr int WIDE_AUX_PER_PATH = MWIN_W * 6 + 24 * 4 + 16 * 4;
 
 template <int L>
 struct WideLds {
     uint64_t exp_tab[ES_EXP_TAB_WORDS];
-    double   candm[2 * L];
-    double   sp[2][L];                  // softplus pair of the even sibling, by slot
-    uint32_t betaL[L][33];              // +1 pad: lanes hit different banks
-    uint32_t curb[L][17];
-    uint16_t sidx[2 * L];               // candidate index travelling with its metric through the sort
+    double   low[6][L];                 // depth 8 (rows 0..3) and depth 9 (rows 4, 5), by slot
+    double   skey[2][2 * L];            // cross-wave sort stages and the read-out, double-buffered
+    double   xsp[2][2][L];              // published at a sort (double-buffered by information index): softplus pair,
+    uint64_t xpa[2][L];                 // ... LLR-tree slot pointers,
+    uint64_t xpb[2][L];                 // ... partial-sum slot pointers | depth-9 pointer << 40 | window ancestor << 48,
+    uint32_t xb0[2][L];                 // ... partial sums of 1..16 bits,
+    uint32_t xhist[2][L];               // ... bits of the current trace-back window
+    uint32_t betaM[7][L];               // partial-sum blocks of 32 (row 0), 64 (1, 2), 128 bits (3..6), by slot
+    uint16_t sidx[2][2 * L];
     uint16_t dpos[KINFO];
-    uint8_t  ptrA[2][NLEV + 1][L];
-    uint8_t  ptrB[2][NLEV + 1][L];
     uint32_t hardw[32];
     uint8_t  hbytes[56];
     int      flag;
 };
 
+__device__ __forceinline__ uint64_t p8_set(uint64_t w, int k, int v) { const int sh = 8 * k; return (w & ~(255ULL << sh)) | ((uint64_t)(uint32_t)v << sh); }
+__device__ __forceinline__ int p8_get(uint64_t w, int k) { return (int)((w >> (8 * k)) & 255ULL); }
+
+// lane l <-> lane l ^ D inside a wave, D a constant after unrolling
+__device__ __forceinline__ int wxor_b32(int v, int D)
+{
+    switch (D) {
+        case 1:  return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+        case 2:  return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+        case 4:  return __builtin_amdgcn_ds_swizzle(v, 0x101F);                // bit mode: xor 4
+        case 8:  return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);    // row_ror:8
+        case 16: return __builtin_amdgcn_ds_swizzle(v, 0x401F);                // bit mode: xor 16
+        default: return __shfl_xor(v, 32);
+    }
+}
+__device__ __forceinline__ double wxor_f64(double x, int D)
+{
+    uint64_t u; __builtin_memcpy(&u, &x, 8);
+    const uint32_t lo = (uint32_t)wxor_b32((int)(uint32_t)u, D);
+    const uint32_t hi = (uint32_t)wxor_b32((int)(uint32_t)(u >> 32), D);
+    u = ((uint64_t)hi << 32) | lo;
+    double r; __builtin_memcpy(&r, &u, 8); return r;
+}
+
+__device__ __forceinline__ bool cand_before(double ka, uint32_t ia, double kb, uint32_t ib) { return (ka < kb) || (ka == kb && ia < ib); }
+
+// Bitonic network over 2L (key, index) pairs, element e = 2 * lane + b held as (k0, i0) / (k1, i1); ascending on exit.
 template <int L>
-__global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
+__device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, uint32_t& i1, const int p, WideLds<L>& W, int& buf)
+{
+    #pragma unroll
+    for (int k = 2; k <= 2 * L; k <<= 1) {
+        const bool asc = ((2 * p) & k) == 0;                     // k == 2L: always ascending
+        #pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j == 1) {                                        // partner = the lane's other element
+                const bool sw = cand_before(k1, i1, k0, i0) == asc;
+                const double tk = sw ? k1 : k0; const uint32_t ti = sw ? i1 : i0;
+                k1 = sw ? k0 : k1; i1 = sw ? i0 : i1; k0 = tk; i0 = ti;
+            } else {
+                const int dl = j >> 1;                           // partner lane p ^ dl, same b
+                const bool take_min = (((p & dl) == 0) == asc);
+                double ok0, ok1; uint32_t oi0, oi1;
+                if (dl >= 64) {
+                    W.skey[buf][2 * p] = k0; W.skey[buf][2 * p + 1] = k1;
+                    W.sidx[buf][2 * p] = (uint16_t)i0; W.sidx[buf][2 * p + 1] = (uint16_t)i1;
+                    __syncthreads();
+                    const int o = p ^ dl;
+                    ok0 = W.skey[buf][2 * o]; ok1 = W.skey[buf][2 * o + 1];
+                    oi0 = W.sidx[buf][2 * o]; oi1 = W.sidx[buf][2 * o + 1];
+                    buf ^= 1;
+                } else {
+                    ok0 = wxor_f64(k0, dl); ok1 = wxor_f64(k1, dl);
+                    oi0 = (uint32_t)wxor_b32((int)i0, dl); oi1 = (uint32_t)wxor_b32((int)i1, dl);
+                }
+                const bool m0 = cand_before(k0, i0, ok0, oi0) == take_min;   // keep mine?
+                const bool m1 = cand_before(k1, i1, ok1, oi1) == take_min;
+                k0 = m0 ? k0 : ok0; i0 = m0 ? i0 : oi0;
+                k1 = m1 ? k1 : ok1; i1 = m1 ? i1 : oi1;
+            }
+        }
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     WideLds<L>& W = *reinterpret_cast<WideLds<L>*>(smem_raw);
@@ -72,7 +142,15 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
     __syncthreads();
     const uint64_t* tab = W.exp_tab;
     double* const A = a.alpha + (long long)blockIdx.x * N * L;       // element e of slot s at A[e*L + s]
-    uint16_t* const TB = a.tb + (long long)blockIdx.x * KINFO * L;
+    unsigned char* const aux = a.aux + (long long)blockIdx.x * WIDE_AUX_PER_PATH * L;
+    uint32_t* const TBW = reinterpret_cast<uint32_t*>(aux);                          // [14][L] window bits (first = MSB)
+    uint32_t* const BG = TBW + MWIN_W * L;                                           // [24][L] partial-sum blocks of 256 (rows 0..7) and 512 bits (8..23), by slot
+    uint32_t* const CB = BG + 24 * L;                                                // [16][L] fold scratch, own column only
+    uint16_t* const TBA = reinterpret_cast<uint16_t*>(CB + 16 * L);                  // [14][L] path at the window's start
+
+    // partial-sum word `wi` (block of 32*Wd bits at words [Wd, 2Wd)) of slot s
+    auto beta_ld = [&](int wi, int s) -> uint32_t { return wi < 8 ? W.betaM[wi - 1][s] : BG[(wi - 8) * L + s]; };
+    auto beta_st = [&](int wi, int s, uint32_t v) { if (wi < 8) W.betaM[wi - 1][s] = v; else BG[(wi - 8) * L + s] = v; };
 
     for (long long f = blockIdx.x; f < a.B; f += gridDim.x) {
         const float* llr32 = (const float*)a.llr + f * N;
@@ -111,7 +189,7 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
         }
         __syncthreads();
         if (p == 0) {
-            const int ok = crc8_bytes_w(W.hbytes, ES_INFO_BYTES) == W.hbytes[ES_INFO_BYTES];
+            const int ok = crc8_bytes(W.hbytes, ES_INFO_BYTES) == W.hbytes[ES_INFO_BYTES];
             W.flag = ok;
             a.hard_ok[f] = (uint8_t)ok;
         }
@@ -126,208 +204,230 @@ __global__ __launch_bounds__(L) void es_scl_wide_kernel(WideArgs a)
         }
 
         // ---------------- list decoding (fastpolar.py:278-330)
-        int cur = 0;                                   // which pointer table is live
-        for (int d = 0; d <= NLEV; ++d) { W.ptrA[0][d][p] = 0; W.ptrB[0][d][p] = 0; }
-        double metric = 0.0;
+        uint64_t pa_ = 0;                 // slot of my LLR block at depth d = 1..8: byte d-1 (every path starts as a copy of path 0)
+        uint64_t pb_ = 0;                 // slot of my partial-sum block at depth d = 1..5: byte d-1; byte 5: LLR slot at depth 9
+        uint32_t b0 = 0;                  // partial-sum blocks of S = 1..16 bits, block of S bits at bit S
+        uint32_t hist = 0, anc = 0;       // trace-back window
+        double metric = 0.0, lam = 0.0, sp_diff = 0.0, sp_sum = 0.0, lp_odd = 0.0;
         int cnt = 1, info_idx = 0;
+        bool dirty = false;               // shared slots may still be being read by a wave that is behind (block-uniform)
         __syncthreads();
 
         for (int i = 0; i < N; ++i) {
-            const int top = (i == 0) ? 1 : NLEV - __builtin_ctz((unsigned)i);
-            const int sp_slot = W.ptrA[cur][NLEV][p];
-            for (int d = top; d <= NLEV; ++d) {
-                const int S = N >> d;
-                const bool is_g = (i >> (NLEV - d)) & 1;
-                const int ps = W.ptrA[cur][d - 1][p];
-                const int bs = W.ptrB[cur][d][p];
-                const double* par = A + (long long)(2 * S) * L + ps;          // depth d-1 block at elements [2S, 4S)
-                double* dst = A + (long long)S * L + p;                        // depth d block at elements [S, 2S)
-                auto ld_pair = [&](int j, double& pa, double& pb) {
-                    if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
-                    else { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; }
-                };
-                if (is_g) {
-                    int j = 0;
-                    for (; j + 4 <= S; j += 4) {                             // four independent load pairs in flight
-                        double pa[4], pb[4];
-                        #pragma unroll
-                        for (int u = 0; u < 4; ++u) ld_pair(j + u, pa[u], pb[u]);
-                        #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const uint32_t wbits = W.betaL[bs][(S + j + u) >> 5];
-                            dst[(long long)(j + u) * L] = es_polar_g(pa[u], pb[u], (wbits >> ((S + j + u) & 31)) & 1u);
-                        }
-                    }
-                    for (; j < S; ++j) {
-                        double pa, pb; ld_pair(j, pa, pb);
-                        const uint32_t wbits = W.betaL[bs][(S + j) >> 5];
-                        dst[(long long)j * L] = es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u);
-                    }
-                } else if (d == NLEV) {
-                    const double pa = par[0], pb = par[(long long)L];
-                    double sd, ss;
-                    dst[0] = es_polar_f_sp(pa, pb, tab, &sd, &ss);
-                    W.sp[0][p] = sd; W.sp[1][p] = ss;
-                } else if (i == 0) {
-                    // first chain: every path is still a copy of path 0, so the node is computed once, the lanes
-                    // sharing its S elements, into slot 0, and every path points at it
+            const bool frozen = (a.frozen.w[i >> 5] >> (i & 31)) & 1u;
+            if (i == 0) {
+                // First chain: every path is still a copy of path 0, so each node is computed once, the lanes sharing
+                // its elements, into slot 0 (a barrier per depth here: lanes read what other lanes wrote).
+                for (int d = 1; d <= 7; ++d) {
+                    const int S = N >> d;
                     for (int j = p; j < S; j += L) {
                         double pa, pb;
                         if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
                         else { pa = A[(long long)(2 * S + j) * L]; pb = A[(long long)(2 * S + j + S) * L]; }
                         A[(long long)(S + j) * L] = es_polar_f(pa, pb, tab);
                     }
-                } else {
-                    double pa, pb;                                           // operands of element j+1 are loaded while f(j) runs
-                    ld_pair(0, pa, pb);
-                    for (int j = 0; j < S; ++j) {
-                        double na = 0.0, nb = 0.0;
-                        if (j + 1 < S) ld_pair(j + 1, na, nb);
-                        dst[(long long)j * L] = es_polar_f(pa, pb, tab);
-                        pa = na; pb = nb;
-                    }
+                    __syncthreads();
                 }
-                __threadfence_block();
+                if (p < 4) W.low[p][0] = es_polar_f(A[(long long)(8 + p) * L], A[(long long)(12 + p) * L], tab);
                 __syncthreads();
-                W.ptrA[cur][d][p] = (uint8_t)((i == 0 && d != NLEV) ? 0 : p);
+                if (p < 2) W.low[4 + p][0] = es_polar_f(W.low[p][0], W.low[p + 2][0], tab);
+                __syncthreads();
+                lam = es_polar_f_sp(W.low[4][0], W.low[5][0], tab, &sp_diff, &sp_sum);
+                dirty = true;
+            } else {
+                const int top = NLEV - __builtin_ctz((unsigned)i);
+                if (top <= 9 && dirty) { __syncthreads(); dirty = false; }      // this step writes slots
+                // --- depths top..7: slab to slab, the lane walks the node
+                for (int d = top; d <= 7; ++d) {
+                    const int S = N >> d;
+                    const bool is_g = (i >> (NLEV - d)) & 1;
+                    const int ps = (d > 1) ? p8_get(pa_, d - 2) : 0;
+                    const double* par = A + (long long)(2 * S) * L + ps;          // depth d-1 block at elements [2S, 4S)
+                    double* dst = A + (long long)S * L + p;                        // depth d block at elements [S, 2S)
+                    auto ld_pair = [&](int j, double& pa, double& pb) {
+                        if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
+                        else { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; }
+                    };
+                    if (is_g) {
+                        const int bs = (d <= 5) ? p8_get(pb_, d - 1) : 0;
+                        for (int j0 = 0; j0 < S; j0 += 32) {
+                            uint32_t wbits; int nb;
+                            if (S >= 32) { wbits = beta_ld((S + j0) >> 5, bs); nb = 32; }
+                            else { wbits = b0 >> S; nb = S; }
+                            for (int u = 0; u < nb; u += 4) {                      // four independent load pairs in flight
+                                double xa[4], xb[4];
+                                #pragma unroll
+                                for (int v = 0; v < 4; ++v) ld_pair(j0 + u + v, xa[v], xb[v]);
+                                #pragma unroll
+                                for (int v = 0; v < 4; ++v) dst[(long long)(j0 + u + v) * L] = es_polar_g(xa[v], xb[v], (wbits >> (u + v)) & 1u);
+                            }
+                        }
+                    } else {
+                        double pa, pb;                                           // operands of element j+1 are loaded while f(j) runs
+                        ld_pair(0, pa, pb);
+                        for (int j = 0; j < S; ++j) {
+                            double na = 0.0, nb = 0.0;
+                            if (j + 1 < S) ld_pair(j + 1, na, nb);
+                            dst[(long long)j * L] = es_polar_f(pa, pb, tab);
+                            pa = na; pb = nb;
+                        }
+                    }
+                    pa_ = p8_set(pa_, d - 1, p);
+                }
+                // --- depth 8: slab -> LDS
+                if (top <= 8) {
+                    const double* par = A + (long long)8 * L + p8_get(pa_, 6);
+                    double x[8];
+                    #pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = par[(long long)u * L];
+                    if ((i >> 2) & 1) {
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j) W.low[j][p] = es_polar_g(x[j], x[j + 4], (b0 >> (4 + j)) & 1u);
+                    } else {
+                        #pragma unroll 2
+                        for (int j = 0; j < 4; ++j) W.low[j][p] = es_polar_f(x[j], x[j + 4], tab);
+                    }
+                    pa_ = p8_set(pa_, 7, p);
+                }
+                // --- depth 9: LDS -> LDS
+                if (top <= 9) {
+                    const int ps = p8_get(pa_, 7);
+                    const double x0 = W.low[0][ps], x1 = W.low[1][ps], x2 = W.low[2][ps], x3 = W.low[3][ps];
+                    if ((i >> 1) & 1) {
+                        W.low[4][p] = es_polar_g(x0, x2, (b0 >> 2) & 1u);
+                        W.low[5][p] = es_polar_g(x1, x3, (b0 >> 3) & 1u);
+                    } else {
+                        W.low[4][p] = es_polar_f(x0, x2, tab);
+                        W.low[5][p] = es_polar_f(x1, x3, tab);
+                    }
+                    pb_ = p8_set(pb_, 5, p);
+                }
+                // --- depth 10: LDS -> register
+                {
+                    const int ps = p8_get(pb_, 5);
+                    const double xa = W.low[4][ps], xb = W.low[5][ps];
+                    if (i & 1) lam = es_polar_g(xa, xb, (b0 >> 1) & 1u);
+                    else lam = es_polar_f_sp(xa, xb, tab, &sp_diff, &sp_sum);
+                }
+                dirty = true;
             }
-            const double lam = A[(long long)1 * L + p];
 
-            const bool frozen = (a.frozen.w[i >> 5] >> (i & 31)) & 1u;
+            // --- decision
             const double al = __builtin_fabs(lam);
             double lp;
-            if (i & 1) {
-                const uint32_t ub = (W.betaL[W.ptrB[cur][NLEV][p]][0] >> 1) & 1u;
-                lp = W.sp[ub ? 0 : 1][sp_slot];
-            } else {
-                lp = es_softplus_neg(-al, tab);
-            }
+            if (i & 1) lp = lp_odd;                                  // set when the even sibling was decided
+            else lp = es_softplus_neg(-al, tab);
             const uint32_t pref = (lam >= 0.0) ? 1u : 0u;
             uint32_t bit = 0;
-            if (frozen) {
+            if (frozen) {                                             // fastpolar.py:281-286
                 double pen = lp;
                 if (pref != 0u) pen = lp + al;
                 metric = metric + pen;
-            } else {
-                const double m0 = metric + ((pref != 0u) ? lp + al : lp);
-                const double m1 = metric + ((pref != 1u) ? lp + al : lp);
-                // the 2*cnt candidates (path order, bit 0 then bit 1) sorted by (metric, candidate index) = Python's
-                // stable list.sort: bitonic network on (key, index) pairs in LDS, one compare-exchange per lane and
-                // stage.  Stages whose partner distance stays inside a wave's 128 elements need only a wave fence.
+                lp_odd = sp_sum;                                      // sibling g = b + a when this bit is 0
+            } else {                                                  // fastpolar.py:288-330
                 const bool live = p < cnt;
                 const int nc = 2 * cnt;
-                int nsort = 2; while (nsort < nc) nsort <<= 1;
-                W.candm[2 * p] = live ? m0 : __builtin_inf(); W.candm[2 * p + 1] = live ? m1 : __builtin_inf();
-                W.sidx[2 * p] = live ? (uint16_t)(2 * p) : (uint16_t)0xFFFF; W.sidx[2 * p + 1] = live ? (uint16_t)(2 * p + 1) : (uint16_t)0xFFFF;
-                __syncthreads();
-                for (int k = 2; k <= nsort; k <<= 1) {
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        if (j >= 128) __syncthreads();
-                        if (2 * p < nsort) {
-                            const int lo = 2 * j * (p / j) + (p % j), hi = lo + j;
-                            const double ka = W.candm[lo], kb = W.candm[hi];
-                            const uint16_t ia = W.sidx[lo], ib = W.sidx[hi];
-                            const bool a_first = (ka < kb) || (ka == kb && ia < ib);
-                            const bool asc = (lo & k) == 0;
-                            if (a_first != asc) { W.candm[lo] = kb; W.candm[hi] = ka; W.sidx[lo] = ib; W.sidx[hi] = ia; }
-                        }
-                        if (j >= 128) __syncthreads();
-                        else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-                    }
-                }
+                double k0 = live ? metric + ((pref != 0u) ? lp + al : lp) : __builtin_inf();
+                double k1 = live ? metric + ((pref != 1u) ? lp + al : lp) : __builtin_inf();
+                uint32_t i0 = live ? (uint32_t)(2 * p) : 0xFFFFu, i1 = live ? (uint32_t)(2 * p + 1) : 0xFFFFu;
+                // publish what follows a path through the sort
+                const int xb = info_idx & 1;
+                const bool wstart = (info_idx & 31) == 0;
+                W.xpa[xb][p] = pa_;
+                W.xpb[xb][p] = pb_ | ((uint64_t)(wstart ? (uint32_t)p : anc) << 48);
+                W.xb0[xb][p] = b0;
+                W.xhist[xb][p] = wstart ? 0u : hist;
+                if (!(i & 1)) { W.xsp[xb][0][p] = sp_diff; W.xsp[xb][1][p] = sp_sum; }
+                int buf = 0;
+                wide_sort<L>(k0, i0, k1, i1, p, W, buf);
+                W.skey[buf][2 * p] = k0; W.skey[buf][2 * p + 1] = k1;
+                W.sidx[buf][2 * p] = (uint16_t)i0; W.sidx[buf][2 * p + 1] = (uint16_t)i1;
                 __syncthreads();
                 const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= L: lists of any size run on the next power of two's kernel
-                const int myr = p < keep ? p : 0;
-                const int myc = W.sidx[myr];
-                const double mym = W.candm[myr];
-                const int parent = myc >> 1;
-                bit = (uint32_t)(myc & 1);
-                metric = mym;
-                const int nxt = cur ^ 1;
-                #pragma unroll
-                for (int d = 0; d <= NLEV; ++d) {
-                    W.ptrA[nxt][d][p] = W.ptrA[cur][d][parent];
-                    W.ptrB[nxt][d][p] = W.ptrB[cur][d][parent];
-                }
-                if (p < keep) TB[(long long)info_idx * L + p] = (uint16_t)myc;
-                cur = nxt;
+                const int myr = p < keep ? p : 0;                  // dead paths mirror rank 0
+                const uint32_t myc = W.sidx[buf][myr];
+                metric = W.skey[buf][myr];
+                const int parent = (int)(myc >> 1) & (L - 1);
+                bit = myc & 1u;
+                pa_ = W.xpa[xb][parent];
+                const uint64_t t = W.xpb[xb][parent];
+                pb_ = t & 0xFFFFFFFFFFFFULL;
+                anc = (uint32_t)(t >> 48);
+                b0 = W.xb0[xb][parent];
+                hist = (W.xhist[xb][parent] << 1) | bit;
+                if (!(i & 1)) lp_odd = W.xsp[xb][bit ? 0 : 1][parent];
+                if ((info_idx & 31) == 31) { TBW[(info_idx >> 5) * L + p] = hist; TBA[(info_idx >> 5) * L + p] = (uint16_t)anc; }
                 cnt = keep;
                 ++info_idx;
-                __syncthreads();
+                dirty = false;                                     // every wave passed the sort's barriers after its reads
             }
 
-            // partial sums (fastpolar.py:156-183); each lane folds its own path
+            // --- partial sums: fold upward while the node is a right child (fastpolar.py:156-183); each lane its own path
             const int t = __builtin_ctz(~(unsigned)i);
             if (t < NLEV) {
                 uint32_t cw = bit;
                 const int t5 = t < 5 ? t : 5;
                 for (int s = 0; s < t5; ++s) {
                     const int S = 1 << s;
-                    const int bs = W.ptrB[cur][NLEV - s][p];
-                    const uint32_t left = (W.betaL[bs][0] >> S) & ((1u << S) - 1u);
+                    const uint32_t left = (b0 >> S) & ((1u << S) - 1u);
                     cw = (left ^ cw) | (cw << S);
                 }
-                __syncthreads();                       // all reads of dword 0 done before anyone rewrites it
-                if (t <= 5) {
-                    if (t < 5) {
-                        const int Sp = 1 << t;
-                        const uint32_t mask = ((1u << Sp) - 1u) << Sp;
-                        W.betaL[p][0] = (W.betaL[p][0] & ~mask) | (cw << Sp);
-                    } else {
-                        W.betaL[p][1] = cw;
-                    }
+                if (t < 5) {
+                    const int Sp = 1 << t;
+                    const uint32_t mask = ((1u << Sp) - 1u) << Sp;
+                    b0 = (b0 & ~mask) | (cw << Sp);
                 } else {
-                    W.curb[p][0] = cw;
-                    for (int s = 5; s < t; ++s) {
-                        const int Wd = 1 << (s - 5);
-                        const int bs = W.ptrB[cur][NLEV - s][p];
-                        for (int w = 0; w < Wd; ++w) {
-                            const uint32_t c0 = W.curb[p][w];
-                            const uint32_t lf = W.betaL[bs][Wd + w];
-                            W.curb[p][Wd + w] = c0;
-                            W.curb[p][w] = c0 ^ lf;
+                    if (t > 5) {
+                        CB[p] = cw;
+                        for (int s = 5; s < t; ++s) {
+                            const int Wd = 1 << (s - 5);
+                            const int bs = p8_get(pb_, NLEV - s - 1);
+                            for (int w = 0; w < Wd; ++w) {
+                                const uint32_t c0 = CB[w * L + p];
+                                const uint32_t lf = beta_ld(Wd + w, bs);
+                                CB[(Wd + w) * L + p] = c0;
+                                CB[w * L + p] = c0 ^ lf;
+                            }
                         }
                     }
-                    __syncthreads();                   // every path has read the left blocks it needs
+                    if (dirty) { __syncthreads(); dirty = false; }  // the block about to be rewritten may still be being read
                     const int Wp = 1 << (t - 5);
-                    for (int w = 0; w < Wp; ++w) W.betaL[p][Wp + w] = W.curb[p][w];
+                    if (t == 5) beta_st(1, p, cw);
+                    else for (int w = 0; w < Wp; ++w) beta_st(Wp + w, p, CB[w * L + p]);
+                    pb_ = p8_set(pb_, NLEV - t - 1, p);
                 }
-                W.ptrB[cur][NLEV - t][p] = (uint8_t)p;
-                __syncthreads();
             }
         }
 
-        // ---------------- final ordering, trace-back, CRC
-        W.candm[p] = metric;
+        // ---------------- final ordering (fastpolar.py:335), trace-back, CRC
+        __syncthreads();
+        W.skey[0][p] = metric;
         __syncthreads();
         int rank = 0;
         for (int k = 0; k < cnt; ++k) {
-            const double mk = W.candm[k];
+            const double mk = W.skey[0][k];
             rank += ((mk < metric) || (mk == metric && k < p)) ? 1 : 0;
         }
         if (p < cnt) {
             uint8_t* out = a.cand_info + (f * a.lsz + rank) * ES_INFO_BYTES;
             int curp = p;
-            uint32_t acc = 0, reg = 0, last = 0;
-            // trace back from the last information step; bytes come out last-to-first, so the CRC
-            // (which runs first-to-last) is computed in a second pass over the stored bytes
-            for (int tt = KINFO - 1; tt >= 0; --tt) {
-                const uint32_t c = TB[(long long)tt * L + curp];
-                acc |= (c & 1u) << (7 - (tt & 7));
-                curp = (int)(c >> 1);
-                if ((tt & 7) == 0) {
-                    if ((tt >> 3) < ES_INFO_BYTES) out[tt >> 3] = (uint8_t)acc; else last = acc;
-                    acc = 0;
-                }
+            uint32_t wd[MWIN_W];
+            #pragma unroll
+            for (int w = MWIN_W - 1; w >= 0; --w) {
+                wd[w] = TBW[w * L + curp];                        // information bits 32w .. 32w+31, first = MSB
+                curp = (int)TBA[w * L + curp];
             }
-            __threadfence_block();
+            uint32_t reg = 0;
+            #pragma unroll
             for (int k = 0; k < ES_INFO_BYTES; ++k) {
-                reg ^= out[k];
+                const uint32_t byte = (wd[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu;
+                out[k] = (uint8_t)byte;
+                reg ^= byte;
                 #pragma unroll
                 for (int b = 0; b < 8; ++b) reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
             }
             a.cand_metric[f * a.lsz + rank] = metric;
-            a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == last);
+            a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == (wd[MWIN_W - 1] & 0xffu));
         }
         if (p == 0) a.ncand[f] = cnt;
         __syncthreads();
@@ -338,13 +438,17 @@ template <int L>
 int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
 {
     const size_t lds = sizeof(WideLds<L>);
+    static_assert(sizeof(WideLds<256>) * 3 <= 160 * 1024, "three workgroups per CU at L = 256");
     if (!(ctx->wide_attr_mask & (unsigned)L)) {      // per context (= per device): the attribute belongs to the device's copy of the kernel
         ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_scl_wide_kernel<L>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->wide_attr_mask |= (unsigned)L;
     }
+    // One slab slot per workgroup.  The slab is sized in units of the context's largest list (Lm); a shorter list gets Lm / L
+    // times as many slots out of the same bytes, so that the chip holds three waves per SIMD at every list size.
+    const int Lm = es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max);
     long long blocks = B;
-    const long long cap = ctx->wide_slots;
+    const long long cap = (long long)ctx->wide_slots * (Lm / L);
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(es_scl_wide_kernel<L>, dim3((unsigned)blocks), dim3(L), lds, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
@@ -353,14 +457,14 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
 
 }  // namespace
 
-// Scratch for the wide kernel: per resident workgroup 1024*L doubles + 448*L uint16.
+// Scratch for the wide kernel: per resident workgroup 1024*L doubles + WIDE_AUX_PER_PATH*L bytes.
 size_t es_scl_wide_scratch_bytes(const es_ctx* ctx, int* slots_out)
 {
     if (ctx->list_size_max <= 32) { *slots_out = 0; return 0; }
-    const int slots = ctx->num_cu * 2;
-    *slots_out = slots;
     const size_t Lm = (size_t)(es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max));
-    return (size_t)slots * (N * Lm * sizeof(double) + KINFO * Lm * sizeof(uint16_t));
+    const int slots = ctx->num_cu * 3 * (int)(256 / Lm);          // twelve waves per CU at the largest list size
+    *slots_out = slots;
+    return (size_t)slots * (N * Lm * sizeof(double) + (size_t)WIDE_AUX_PER_PATH * Lm);
 }
 
 int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
@@ -371,9 +475,9 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
     WideArgs a{};
     a.llr = llr; a.is_f64 = (dtype == ES_DTYPE_F64); a.B = B;
     a.frozen = ctx->frozen; a.data_pos = ctx->d_data_pos; a.exp_tab = ctx->d_exp_tab;
+    const size_t Lm = (size_t)(es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max));
     a.alpha = reinterpret_cast<double*>(ctx->d_wide_scratch);
-    a.tb = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(ctx->d_wide_scratch) +
-                                       (size_t)ctx->wide_slots * N * (size_t)(es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max)) * sizeof(double));
+    a.aux = reinterpret_cast<unsigned char*>(ctx->d_wide_scratch) + (size_t)ctx->wide_slots * N * Lm * sizeof(double);
     a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
     a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
     a.skip_if_hard_ok = skip_if_hard_ok;

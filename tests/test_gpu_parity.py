@@ -561,9 +561,9 @@ def test_select_kernel_vs_oracle_and_host_rules(engine, oracle, L):
         assert len(seen) >= 3
 
 
-@pytest.mark.parametrize("L", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("L", [1, 2, 4, 8, 16, 24, 32])
 def test_scl_multi_frames_per_wave(engine, oracle, L):
-    """es_scl_multi.hip (16/L frames per wavefront) returns exactly what the one-frame-per-wave kernel and the oracle
+    """es_scl_multi.hip (16/L frames per wavefront; L = 32 as 32 paths x 2 lanes) returns exactly what the one-frame-per-wave kernel and the oracle
     return: random LLRs, clipped LLRs (exact ties), hard-decision hits mixed in (skipped frames inside a wave), a batch
     size that is not a multiple of the frames per wave, float32 and float64 inputs."""
     rng = np.random.default_rng(100 + L)
