@@ -81,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: = --scl-streams)")
     ap.add_argument("--no-side-stream", action="store_true", help="front-end / list-decoder arrangement: LLR on the front-end stream")
     ap.add_argument("--lanes", type=int, default=7, help="pipeline as K independent whole-chain lanes (0: front end + list-decoder streams)")
+    ap.add_argument("--group", type=int, default=16, help="batches per list-decoder launch (grouped pipeline: --front-lanes front streams, --scl-streams decoder streams, one lane per path); 0 = the whole-chain lanes of --lanes")
+    ap.add_argument("--front-lanes", type=int, default=4, help="front-end streams of the grouped pipeline")
     ap.add_argument("--scl-multi", type=int, default=1, help="es_set_option scl_multi for the pipelined headline: -1 auto, 0 one frame per wave, 1 several")
     return ap.parse_args(argv)
 
@@ -223,9 +225,11 @@ def run_rank(a) -> None:
     # A step = one batch through the whole hot path.  Batches are independent, so the engine's streaming pipeline
     # (echoseal_amd.engine.DecodePipeline) keeps two in flight: the front end of batch k+2 starts when batch k leaves,
     # beside the list decoder of batch k+1.  Every step's outputs are complete at the final sync.
-    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None, lanes=a.lanes, side_stream=not a.no_side_stream)
-    for e in pipe.scl_engs:
-        e.set_option("scl_multi", a.scl_multi)
+    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None, lanes=a.front_lanes if a.group else a.lanes,
+                          side_stream=not a.no_side_stream, group=a.group)
+    if not a.group:
+        for e in pipe.scl_engs:
+            e.set_option("scl_multi", a.scl_multi)
 
     def step(k=None):
         sync_res, _llr, res, _done = pipe.submit(frames_d, band_d, pn_d, xcorr_events=None if k is None else ev[k])
@@ -236,24 +240,29 @@ def run_rank(a) -> None:
     torch.cuda.synchronize()
     lat = []                                   # latency of ONE batch with nothing else in flight, with the list decoder the library
     for e in pipe.scl_engs:                    # picks for a lone 1 024-frame batch (one frame per wave); same streams as the pipeline
-        e.set_option("scl_multi", -1)          # (an extra stream would oversubscribe the eight hardware queues)
-    step(); torch.cuda.synchronize()
+        e.set_option("scl_multi", -1)          # (an extra stream would oversubscribe the eight hardware queues; grouped pipeline: already so)
+    step(); pipe.synchronize(); torch.cuda.synchronize()
     for _ in range(3):
         t1 = time.perf_counter()
         step()
+        pipe.synchronize()                     # (grouped pipeline: decodes the one-batch group)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
     single_ms = 1e3 * min(lat)
-    for e in pipe.scl_engs:
-        e.set_option("scl_multi", a.scl_multi)
+    if not a.group:
+        for e in pipe.scl_engs:
+            e.set_option("scl_multi", a.scl_multi)
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
         res, peaks, npeaks = step(k)
+    pipe.synchronize()                          # (grouped pipeline: decodes the last, possibly incomplete, group)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     xcorr_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if a.steps else float("nan")
     ok_sync = bool(torch.all((npeaks >= 1) & (npeaks < 32)).item() and torch.all(peaks[:, 0] == 0).item())
+    if a.group:
+        res = res.result()
     listed = int((res.ncand > 0).sum().item())
     del res, peaks, npeaks
     pipe.synchronize()
@@ -318,6 +327,8 @@ def run_rank(a) -> None:
         # step runs beside the list decoder of the other (the list decoder's blocks are not persistent: wave slots free up
         # as it proceeds)
         pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes)
+        for e in pipe3.lane_engs:                                # kernels by launch size: 65 536 records -> one lane per path
+            e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
         def c3_lane_step():
             sy, _llr, scl, _done = pipe3.submit(win, band3, pn3, start="peak", select=True)
             return sy, scl
@@ -392,6 +403,8 @@ def run_rank(a) -> None:
         chunk = max(1, min(a.c4_chunk, n4))
 
         pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes)
+        for e in pipe4.lane_engs:
+            e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
 
         def c4_pass(limit=None):
             for c0 in range(0, n4 if limit is None else min(n4, limit), chunk):
@@ -440,7 +453,10 @@ def run_rank(a) -> None:
                        "frames_per_gpu": B, "list_size": L, "frame_len": 1215, "fs": 48000,
                        "world_size": world, "backend": ("nccl (RCCL)" if a.backend == "nccl" else a.backend) if world > 1 else "none (single rank)",
                        "sharding": f"{world} x {B} frames, schedule broadcast from rank 0",
-                       "pipelining": (f"{a.lanes} batches in flight (DecodePipeline, whole-chain lanes: batch k runs band-pass .. list decoder on HIP stream k mod {a.lanes}, "
+                       "pipelining": (f"grouped: the front ends (band-pass .. demodulator) of {a.group} consecutive batches run on {pipe.lanes} HIP streams and fill one LLR buffer, "
+                                      f"ONE list-decoder launch (one lane per path, 64/L frames per wave) decodes the group on one of {len(pipe.backs)} further streams; "
+                                      f"up to {len(pipe.backs) + 1} groups in flight, the last (incomplete) group is decoded inside the timed region") if a.group else
+                                     (f"{a.lanes} batches in flight (DecodePipeline, whole-chain lanes: batch k runs band-pass .. list decoder on HIP stream k mod {a.lanes}, "
                                       f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')})") if a.lanes else
                                      f"{a.scl_streams} batches in flight (DecodePipeline: front-end stream + {a.scl_streams} list-decoder streams)",
                        "single_batch_latency_ms": single_ms,
@@ -458,7 +474,7 @@ def run_rank(a) -> None:
         else:
             out["roofline"] = c2_roof                     # no c3 leg in this run: the fused sync launch of the headline steps
         scl_pmc = _profile_json("r02_scl_pmc.json") or {}
-        kname = "es_scl_multi_kernel<8>" if (a.lanes and a.scl_multi == 1) else "es_scl_kernel<8>"
+        kname = "es_scl_wide_kernel<64,8>" if a.group else "es_scl_multi_kernel<8>" if (a.lanes and a.scl_multi == 1) else "es_scl_kernel<8>"
         key = next((k for k in scl_pmc if k.startswith(kname)), None)
         if key and L == 8:
             vi = scl_pmc[key]["per_frame"]["valu_instructions"]

@@ -63,7 +63,13 @@ es_ctx* es_create(int device, int list_size_max)
         es_destroy(ctx);
         return nullptr;
     }
+    ctx->wide_enabled = list_size_max > 32;
     ctx->wide_scratch_bytes = es_scl_wide_scratch_bytes(ctx, &ctx->wide_slots);
+    if (hipMalloc(&ctx->d_wide_slot_bits, 128 * sizeof(unsigned)) != hipSuccess || hipMemset(ctx->d_wide_slot_bits, 0, 128 * sizeof(unsigned)) != hipSuccess) {
+        g_create_err = "device allocation of the slab slot bitmap failed";
+        es_destroy(ctx);
+        return nullptr;
+    }
     if (ctx->wide_scratch_bytes && hipMalloc(&ctx->d_wide_scratch, ctx->wide_scratch_bytes) != hipSuccess) {
         g_create_err = "device allocation of the wide-list SCL scratch slab failed";
         ctx->d_wide_scratch = nullptr;
@@ -84,6 +90,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_slot_bits) (void)hipFree(ctx->d_slot_bits);
     if (ctx->d_ws_corr) (void)hipFree(ctx->d_ws_corr);
     if (ctx->d_wide_scratch) (void)hipFree(ctx->d_wide_scratch);
+    if (ctx->d_wide_slot_bits) (void)hipFree(ctx->d_wide_slot_bits);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
     if (ctx->d_hdr_pn) (void)hipFree(ctx->d_hdr_pn);
     if (ctx->d_nflag) (void)hipFree(ctx->d_nflag);
@@ -311,6 +318,14 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     int lp = 1; while (lp < list_size) lp <<= 1;              // the kernels are built for powers of two; any size runs on the next one
+    // One lane per path, 64/L frames per wave (es_scl_wide.hip): fewest instructions per frame (every lane busy at every tree depth) but
+    // a wave carries 64/L frames through the whole decode, so by itself it needs a batch that gives every SIMD three such waves (a pipeline that keeps several launches in flight forces it earlier): measured at
+    // L = 8, 2.0 against 1.8 M frames/s at 16 384 frames, 2.7 against 2.2 M at 73 728, and 0.2 against 0.46 M at 1 000.  Chosen by
+    // batch size when the context has that kernel's slab (list_size_max > 32, or es_set_option "scl_lane_slab").
+    const bool lane_auto = ctx->scl_lanes == 0 && ctx->scl_multi < 0 && ctx->d_wide_scratch && lp >= 2 && (long long)B * lp / 64 >= 3LL * ctx->num_cu * 4;
+    if ((ctx->scl_lanes == 1 && ctx->scl_multi != 0) || lane_auto)
+        return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
+                                  cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     if (lp <= 32) {
         // several frames per wave (es_scl_multi.hip) once the batch yields enough such waves (16/L frames each).  One
         // frame per wave wastes more lanes the shorter the list is, so the break-even moves down with L: measured
@@ -377,9 +392,20 @@ int es_set_option(es_ctx* ctx, const char* name, int value)
         ctx->scl_multi = value;
         return ES_OK;
     }
-    if (std::strcmp(name, "scl_lanes") == 0) {
-        if (value != 0 && value != 2 && value != 4) return fail(ctx, ES_EINVAL, "es_set_option: scl_lanes takes 0 (by batch size), 2 or 4");
-        ctx->scl_lanes = value;
+    if (std::strcmp(name, "scl_lanes") == 0 || std::strcmp(name, "scl_lane_slab") == 0) {
+        const bool slab_only = name[9] == '_';
+        if (slab_only ? (value != 1) : (value != 0 && value != 1 && value != 2 && value != 4))
+            return fail(ctx, ES_EINVAL, slab_only ? "es_set_option: scl_lane_slab takes 1" : "es_set_option: scl_lanes takes 0 (by batch size), 1, 2 or 4");
+        if (value == 1 && !ctx->d_wide_scratch) {             // one lane per path: the slab of es_scl_wide.hip (allocated here, never in an enqueue call)
+            DeviceGuard g(ctx->device);
+            ctx->wide_enabled = true;
+            ctx->wide_scratch_bytes = es_scl_wide_scratch_bytes(ctx, &ctx->wide_slots);
+            if (hipMalloc(&ctx->d_wide_scratch, ctx->wide_scratch_bytes) != hipSuccess) {
+                ctx->d_wide_scratch = nullptr; ctx->wide_enabled = false;
+                return fail(ctx, ES_ENOMEM, "es_set_option: device allocation of the lane-per-path scratch slab failed");
+            }
+        }
+        if (!slab_only) ctx->scl_lanes = value;
         return ES_OK;
     }
     return fail(ctx, ES_EINVAL, "es_set_option: unknown option");

@@ -36,12 +36,14 @@ struct es_ctx {
     double* d_scl_scratch = nullptr;  size_t scl_scratch_bytes = 0;
     unsigned* d_slot_bits = nullptr;  /* bitmap of the slab slots of es_scl_multi_kernel (one bit per resident block) */
     double* d_ws_corr = nullptr;      size_t ws_corr_bytes = 0;
-    void*   d_wide_scratch = nullptr; size_t wide_scratch_bytes = 0; int wide_slots = 0;   /* list sizes 64..256 */
+    void*   d_wide_scratch = nullptr; size_t wide_scratch_bytes = 0; int wide_slots = 0;   /* lane-per-path list decoder (es_scl_wide.hip): list sizes 64..256, and shorter lists with scl_lanes = 1 */
+    bool    wide_enabled = false;
+    unsigned* d_wide_slot_bits = nullptr;                 /* its slab slot bitmap (128 words: up to 3 072 one-wave blocks) */
     uint8_t* d_sbox = nullptr;        /* AES S-box (es_schedule_batch) */
     uint8_t* d_hdr_pn = nullptr;      /* packed header PN (es_tx_frames_batch) */
     int*     d_nflag = nullptr;       /* records the fused sync kernel handed to the float64 kernels (per call) */
     bool pick_attr_set = false;       /* per-device kernel attributes already raised for this context's device */
-    unsigned wide_attr_mask = 0;      /* bit per wide-list kernel instantiation (64 / 128 / 256) */
+    unsigned wide_attr_mask = 0;      /* bit per instantiation of the lane-per-path list decoder (its list capacity 1 .. 256) */
     /* tuning (es_set_option) */
     int scl_lanes = 0;                /* lanes per path of the multi-frame list decoder: 4 (16 paths per wave), 2 (32 paths per wave), 0 = by batch size */
     int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
@@ -56,6 +58,7 @@ struct es_ctx {
         }                                                                               \
     } while (0)
 
+static inline int es_wide_lanes_max(const es_ctx*) { return 256; }   /* lanes of the largest block of es_scl_wide.hip: the slab is sized in such blocks */
 /* kernels exist for power-of-two list sizes; a context created for list_size_max serves every size up to the next one */
 static inline int es_list_cap(int lmax) { int c = 1; while (c < lmax) c <<= 1; return c; }
 

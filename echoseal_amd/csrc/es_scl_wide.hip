@@ -27,6 +27,12 @@
 // and only when no sort has happened since those reads (`dirty`).  A depth-by-depth barrier is not needed: within a
 // step a path reads what it has itself just written.
 //
+// The same kernel serves SHORT lists (LF = 1..64 paths per frame) as `lane per path, several frames per wave`: a block of
+// 256 lanes then carries 256/LF frames, every wave is its own group (64/LF whole frames, the sort network stops at the
+// frame's 2*LF candidates, every "barrier" is a wave fence) -- all 64 lanes are busy at every tree depth, which the
+// lanes-share-a-path kernels (es_scl.hip, es_scl_multi.hip) cannot offer at the bottom of the tree.  The price is latency: a
+// wave carries 64/LF frames through the whole decode, so this mapping is for large batches (es_set_option "scl_lanes" = 1).
+//
 // Values are bit-identical to the reference list decoder for the same reason as in es_scl.hip (es_math.h).
 #include "es_scl_common.h"
 
@@ -43,28 +49,29 @@ struct WideArgs {
     uint8_t* cand_info; double* cand_metric; uint8_t* cand_ok; int32_t* ncand;
     int skip_if_hard_ok;
     int lsz;                                  // the caller's list size (<= L)
+    unsigned* slot_bits; int n_slots, slot_words;   // bitmap of slab slots (one per resident block), as in es_scl_multi.hip
 };
 
 constexpr int MWIN_W = KINFO / 32;            // trace-back windows
 // aux slab per path: windows 14 x (4 + 2) B, partial-sum blocks of 256 / 512 bits 24 x 4 B, fold scratch 16 x 4 B
 constexpr int WIDE_AUX_PER_PATH = MWIN_W * 6 + 24 * 4 + 16 * 4;
 
-template <int L>
+// NB = 2: buffers that a wave may still be reading while another wave is already a sort further (several waves per frame);
+// a block that is one wave runs in order and needs one of each.
+template <int L, int NB>
 struct WideLds {
     uint64_t exp_tab[ES_EXP_TAB_WORDS];
     double   low[6][L];                 // depth 8 (rows 0..3) and depth 9 (rows 4, 5), by slot
-    double   skey[2][2 * L];            // cross-wave sort stages and the read-out, double-buffered
-    double   xsp[2][2][L];              // published at a sort (double-buffered by information index): softplus pair,
-    uint64_t xpa[2][L];                 // ... LLR-tree slot pointers,
-    uint64_t xpb[2][L];                 // ... partial-sum slot pointers | depth-9 pointer << 40 | window ancestor << 48,
-    uint32_t xb0[2][L];                 // ... partial sums of 1..16 bits,
-    uint32_t xhist[2][L];               // ... bits of the current trace-back window
+    double   skey[NB][2 * L];           // cross-wave sort stages and the read-out
+    double   xsp[NB][2][L];             // published at a sort (NB = 2: double-buffered by information index): softplus pair,
+    uint64_t xpa[NB][L];                // ... LLR-tree slot pointers,
+    uint64_t xpb[NB][L];                // ... partial-sum slot pointers | depth-9 pointer << 40 | window ancestor << 48,
+    uint32_t xb0[NB][L];                // ... partial sums of 1..16 bits,
+    uint32_t xhist[NB][L];              // ... bits of the current trace-back window
     uint32_t betaM[7][L];               // partial-sum blocks of 32 (row 0), 64 (1, 2), 128 bits (3..6), by slot
-    uint16_t sidx[2][2 * L];
-    uint16_t dpos[KINFO];
-    uint32_t hardw[32];
-    uint8_t  hbytes[56];
+    uint16_t sidx[NB][2 * L];
     int      flag;
+    // (the hard decision's 184 bytes borrow the first wave's cells of skey[0])
 };
 
 __device__ __forceinline__ uint64_t p8_set(uint64_t w, int k, int v) { const int sh = 8 * k; return (w & ~(255ULL << sh)) | ((uint64_t)(uint32_t)v << sh); }
@@ -94,12 +101,13 @@ __device__ __forceinline__ double wxor_f64(double x, int D)
 __device__ __forceinline__ bool cand_before(double ka, uint32_t ia, double kb, uint32_t ib) { return (ka < kb) || (ka == kb && ia < ib); }
 
 // Bitonic network over 2L (key, index) pairs, element e = 2 * lane + b held as (k0, i0) / (k1, i1); ascending on exit.
-template <int L>
-__device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, uint32_t& i1, const int p, WideLds<L>& W, int& buf)
+// (LF < L: independent networks over aligned groups of LF lanes -- one per frame; pl = lane index within the frame)
+template <int L, int LF>
+__device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, uint32_t& i1, const int p, const int pl, WideLds<L, (LF > 64 ? 2 : 1)>& W, int& buf)
 {
     #pragma unroll
-    for (int k = 2; k <= 2 * L; k <<= 1) {
-        const bool asc = ((2 * p) & k) == 0;                     // k == 2L: always ascending
+    for (int k = 2; k <= 2 * LF; k <<= 1) {
+        const bool asc = ((2 * pl) & k) == 0;                    // k == 2 LF: always ascending
         #pragma unroll
         for (int j = k >> 1; j >= 1; j >>= 1) {
             if (j == 1) {                                        // partner = the lane's other element
@@ -108,7 +116,7 @@ __device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, 
                 k1 = sw ? k0 : k1; i1 = sw ? i0 : i1; k0 = tk; i0 = ti;
             } else {
                 const int dl = j >> 1;                           // partner lane p ^ dl, same b
-                const bool take_min = (((p & dl) == 0) == asc);
+                const bool take_min = (((pl & dl) == 0) == asc);
                 double ok0, ok1; uint32_t oi0, oi1;
                 if (dl >= 64) {
                     W.skey[buf][2 * p] = k0; W.skey[buf][2 * p + 1] = k1;
@@ -131,112 +139,186 @@ __device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, 
     }
 }
 
-template <int L>
+// hard decision -> butterfly -> data bits -> CRC of one frame by one wave (fastpolar.py:260-268); returns the CRC verdict to every lane
+__device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long ff, int lane, uint32_t* hardw, uint8_t* hbytes, const uint16_t* dpos)
+{
+    const float* l32 = (const float*)a.llr + ff * N;
+    const double* l64 = (const double*)a.llr + ff * N;
+    uint32_t word = 0;
+    for (int c = 0; c < 16; ++c) {
+        const double v = a.is_f64 ? l64[64 * c + lane] : (double)l32[64 * c + lane];
+        const unsigned long long m = __ballot(v > 0.0);
+        if (((lane & 31) >> 1) == c) word = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+    }
+    word ^= (word >> 1) & 0x55555555u;
+    word ^= (word >> 2) & 0x33333333u;
+    word ^= (word >> 4) & 0x0f0f0f0fu;
+    word ^= (word >> 8) & 0x00ff00ffu;
+    word ^= (word >> 16) & 0x0000ffffu;
+    #pragma unroll
+    for (int hw = 1; hw < 32; hw <<= 1) {
+        const uint32_t o = __shfl_xor(word, hw);
+        if (!((lane & 31) & hw)) word ^= o;
+    }
+    if (lane < 32) hardw[lane] = word;
+    wave_fence_lds();
+    if (lane < 56) {
+        uint32_t byte = 0;
+        #pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int pos = dpos[8 * lane + b];
+            byte |= ((hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
+        }
+        hbytes[lane] = (uint8_t)byte;
+    }
+    wave_fence_lds();
+    int ok = 0;
+    if (lane == 0) ok = (crc8_bytes(hbytes, ES_INFO_BYTES) == hbytes[ES_INFO_BYTES]);
+    ok = __shfl(ok, 0);
+    if (lane < ES_INFO_BYTES) a.hard_info[ff * ES_INFO_BYTES + lane] = hbytes[lane];
+    if (lane == 0) a.hard_ok[ff] = (uint8_t)ok;
+    wave_fence_lds();
+    return ok;
+}
+
+// L lanes per block, LF paths per frame.  LF > 64: one frame per block, the block is the group (barrier = __syncthreads).
+// LF <= 64: every wave is a group of 64 / LF whole frames (barrier = wave fence), L / LF frames per block.
+template <int L, int LF>
 __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
 {
+    constexpr bool WAVE = (LF <= 64);                // the block is one wave
+    constexpr int FRG = L / LF;                      // frames per block
+    constexpr int NG = 1;
+    constexpr int NB = WAVE ? 1 : 2;
+    static_assert(LF >= 1 && LF <= L && (L % 64) == 0 && L <= 256 && (WAVE ? L == 64 : L == LF), "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    WideLds<L>& W = *reinterpret_cast<WideLds<L>*>(smem_raw);
-    const int p = threadIdx.x;                       // path == lane
+    WideLds<L, NB>& W = *reinterpret_cast<WideLds<L, NB>*>(smem_raw);
+    const int p = threadIdx.x;                       // slot == lane of the block
+    const int lane = p & 63, wv = p >> 6;
+    const int pl = p % LF;                           // path within its frame
+    const int fp0 = p - pl;                          // slot of the frame's path 0
+    const int gi = 0;
     for (int i = p; i < ES_EXP_TAB_WORDS; i += L) W.exp_tab[i] = a.exp_tab[i];
-    for (int i = p; i < KINFO; i += L) W.dpos[i] = a.data_pos[i];
     __syncthreads();
+    auto group_sync = [&]() { if constexpr (WAVE) wave_fence_global(); else __syncthreads(); };
     const uint64_t* tab = W.exp_tab;
-    double* const A = a.alpha + (long long)blockIdx.x * N * L;       // element e of slot s at A[e*L + s]
-    unsigned char* const aux = a.aux + (long long)blockIdx.x * WIDE_AUX_PER_PATH * L;
+    // ---- claim a slab slot for this block (bit per slot; LDS and registers keep resident blocks <= slots).  Blocks are not
+    // persistent: a block decodes its frames and leaves, so a launch has no tail of half-empty iterations and the wave slots it
+    // frees go to whatever is queued (the front end of the next batches, the next group's list decoder).
+    if (p == 0) {
+        int slot = -1;
+        unsigned w = blockIdx.x % (unsigned)a.slot_words;
+        for (int tries = 0; slot < 0 && tries < (1 << 22); ++tries) {
+            const unsigned v = __hip_atomic_load(&a.slot_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned valid = (w == (unsigned)a.slot_words - 1 && (a.n_slots & 31)) ? ((1u << (a.n_slots & 31)) - 1u) : 0xffffffffu;
+            const unsigned freeb = ~v & valid;
+            if (freeb) {
+                const int bit = __ffs(freeb) - 1;
+                const unsigned old = atomicOr(&a.slot_bits[w], 1u << bit);
+                if (!(old & (1u << bit))) slot = (int)(w * 32u) + bit;
+            } else {
+                w = (w + 1u) % (unsigned)a.slot_words;
+                if (tries > 64) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        W.flag = slot;
+    }
+    __syncthreads();
+    const int slot = W.flag;
+    __syncthreads();
+    if (slot < 0) {                                                    // cannot happen (see the launcher); never spin forever, never fail silently:
+        constexpr int FRB = FRG;                                        // the block's frames read ncand = -1
+        for (long long ff = (long long)blockIdx.x * FRB + p; p < FRB && ff < a.B; ff += a.B) a.ncand[ff] = -1;
+        return;
+    }
+    double* const A = a.alpha + (long long)slot * N * L;             // element e of slot s at A[e*L + s]
+    unsigned char* const aux = a.aux + (long long)slot * WIDE_AUX_PER_PATH * L;
     uint32_t* const TBW = reinterpret_cast<uint32_t*>(aux);                          // [14][L] window bits (first = MSB)
     uint32_t* const BG = TBW + MWIN_W * L;                                           // [24][L] partial-sum blocks of 256 (rows 0..7) and 512 bits (8..23), by slot
     uint32_t* const CB = BG + 24 * L;                                                // [16][L] fold scratch, own column only
-    uint16_t* const TBA = reinterpret_cast<uint16_t*>(CB + 16 * L);                  // [14][L] path at the window's start
+    uint16_t* const TBA = reinterpret_cast<uint16_t*>(CB + 16 * L);                  // [14][L] path (within the frame) at the window's start
 
     // partial-sum word `wi` (block of 32*Wd bits at words [Wd, 2Wd)) of slot s
     auto beta_ld = [&](int wi, int s) -> uint32_t { return wi < 8 ? W.betaM[wi - 1][s] : BG[(wi - 8) * L + s]; };
     auto beta_st = [&](int wi, int s, uint32_t v) { if (wi < 8) W.betaM[wi - 1][s] = v; else BG[(wi - 8) * L + s] = v; };
 
-    for (long long f = blockIdx.x; f < a.B; f += gridDim.x) {
+    uint32_t* const hd_words = reinterpret_cast<uint32_t*>(&W.skey[0][0]);                  // 32 words ...
+    uint8_t* const hd_bytes = reinterpret_cast<uint8_t*>(&W.skey[0][16]);                   // ... and 56 bytes of the hard decision (first wave)
+    const long long n_groups = (a.B + FRG - 1) / FRG;
+    for (long long g = (long long)blockIdx.x * NG + gi; g < n_groups; g += (long long)gridDim.x * NG) {      // one group per wave / block (grid = groups)
+        const long long f_raw = g * FRG + (WAVE ? lane / LF : 0);
+        const bool f_valid = f_raw < a.B;
+        const long long f = f_valid ? f_raw : a.B - 1;          // a missing frame mirrors the last one (never stored)
         const float* llr32 = (const float*)a.llr + f * N;
         const double* llr64 = (const double*)a.llr + f * N;
 
-        // ---------------- hard decision (fastpolar.py:260-268), first wave
-        if (p < 64) {
-            const int lane = p;
-            uint32_t word = 0;
-            for (int c = 0; c < 16; ++c) {
-                const double v = a.is_f64 ? llr64[64 * c + lane] : (double)llr32[64 * c + lane];
-                const unsigned long long m = __ballot(v > 0.0);
-                if (((lane & 31) >> 1) == c) word = (lane & 1) ? (uint32_t)(m >> 32) : (uint32_t)m;
+        // ---------------- hard decision (fastpolar.py:260-268): frame by frame, one wave each
+        uint64_t active_mask = 0;                              // block-uniform: frames that go through the list loop (up to 64 of them)
+        if constexpr (WAVE) {
+            for (int fi = 0; fi < FRG; ++fi) {
+                const long long ff = g * FRG + fi;
+                if (ff >= a.B) break;
+                const int ok = hard_decision_wave(a, ff, lane, hd_words, hd_bytes, a.data_pos);
+                if (ok && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
+                    if (lane == 0) a.ncand[ff] = 0;
+                    #pragma unroll 1
+                    for (int k = lane; k < a.lsz * ES_INFO_BYTES; k += 64) a.cand_info[ff * a.lsz * ES_INFO_BYTES + k] = 0;
+                    #pragma unroll 1
+                    for (int k = lane; k < a.lsz; k += 64) { a.cand_metric[ff * a.lsz + k] = 0.0; a.cand_ok[ff * a.lsz + k] = 0; }
+                } else active_mask |= 1ULL << fi;
             }
-            word ^= (word >> 1) & 0x55555555u;
-            word ^= (word >> 2) & 0x33333333u;
-            word ^= (word >> 4) & 0x0f0f0f0fu;
-            word ^= (word >> 8) & 0x00ff00ffu;
-            word ^= (word >> 16) & 0x0000ffffu;
-            #pragma unroll
-            for (int hw = 1; hw < 32; hw <<= 1) {
-                const uint32_t o = __shfl_xor(word, hw);
-                if (!((lane & 31) & hw)) word ^= o;
+        } else {
+            if (wv == 0) {
+                const int ok = hard_decision_wave(a, f, lane, hd_words, hd_bytes, a.data_pos);
+                if (lane == 0) W.flag = ok;
             }
-            if (lane < 32) W.hardw[lane] = word;
-        }
-        __syncthreads();
-        if (p < 56) {
-            uint32_t byte = 0;
-            #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int pos = W.dpos[8 * p + b];
-                byte |= ((W.hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
-            }
-            W.hbytes[p] = (uint8_t)byte;
-        }
-        __syncthreads();
-        if (p == 0) {
-            const int ok = crc8_bytes(W.hbytes, ES_INFO_BYTES) == W.hbytes[ES_INFO_BYTES];
-            W.flag = ok;
-            a.hard_ok[f] = (uint8_t)ok;
-        }
-        if (p < ES_INFO_BYTES) a.hard_info[f * ES_INFO_BYTES + p] = W.hbytes[p];
-        __syncthreads();
-        if (W.flag && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
-            if (p == 0) a.ncand[f] = 0;
-            for (int k = p; k < a.lsz * ES_INFO_BYTES; k += L) a.cand_info[f * a.lsz * ES_INFO_BYTES + k] = 0;
-            if (p < a.lsz) { a.cand_metric[f * a.lsz + p] = 0.0; a.cand_ok[f * a.lsz + p] = 0; }
             __syncthreads();
-            continue;
+            if (W.flag && a.skip_if_hard_ok) {
+                if (p == 0) a.ncand[f] = 0;
+                for (int k = p; k < a.lsz * ES_INFO_BYTES; k += L) a.cand_info[f * a.lsz * ES_INFO_BYTES + k] = 0;
+                if (p < a.lsz) { a.cand_metric[f * a.lsz + p] = 0.0; a.cand_ok[f * a.lsz + p] = 0; }
+            } else active_mask = 1ULL;
+            __syncthreads();
         }
+        if (active_mask == 0) continue;
+        const bool f_store = f_valid && ((active_mask >> (WAVE ? lane / LF : 0)) & 1ULL);
 
         // ---------------- list decoding (fastpolar.py:278-330)
-        uint64_t pa_ = 0;                 // slot of my LLR block at depth d = 1..8: byte d-1 (every path starts as a copy of path 0)
-        uint64_t pb_ = 0;                 // slot of my partial-sum block at depth d = 1..5: byte d-1; byte 5: LLR slot at depth 9
+        // slot of my LLR block at depth d = 1..8: byte d-1 (every path starts as a copy of its frame's path 0)
+        uint64_t pa_ = (uint64_t)(uint32_t)fp0 * 0x0101010101010101ULL;
+        // slot of my partial-sum block at depth d = 1..5: byte d-1; byte 5: LLR slot at depth 9
+        uint64_t pb_ = (uint64_t)(uint32_t)fp0 * 0x0000010101010101ULL;
         uint32_t b0 = 0;                  // partial-sum blocks of S = 1..16 bits, block of S bits at bit S
         uint32_t hist = 0, anc = 0;       // trace-back window
         double metric = 0.0, lam = 0.0, sp_diff = 0.0, sp_sum = 0.0, lp_odd = 0.0;
         int cnt = 1, info_idx = 0;
-        bool dirty = false;               // shared slots may still be being read by a wave that is behind (block-uniform)
-        __syncthreads();
+        bool dirty = false;               // shared slots may still be being read by a wave that is behind (group-uniform)
+        group_sync();
 
         for (int i = 0; i < N; ++i) {
             const bool frozen = (a.frozen.w[i >> 5] >> (i & 31)) & 1u;
             if (i == 0) {
-                // First chain: every path is still a copy of path 0, so each node is computed once, the lanes sharing
-                // its elements, into slot 0 (a barrier per depth here: lanes read what other lanes wrote).
+                // First chain: the paths of a frame are still copies of its path 0, so each node is computed once, the frame's
+                // lanes sharing its elements, into that path's slot (a barrier per depth here: lanes read what other lanes wrote).
                 for (int d = 1; d <= 7; ++d) {
                     const int S = N >> d;
-                    for (int j = p; j < S; j += L) {
+                    for (int j = pl; j < S; j += LF) {
                         double pa, pb;
                         if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
-                        else { pa = A[(long long)(2 * S + j) * L]; pb = A[(long long)(2 * S + j + S) * L]; }
-                        A[(long long)(S + j) * L] = es_polar_f(pa, pb, tab);
+                        else { pa = A[(long long)(2 * S + j) * L + fp0]; pb = A[(long long)(2 * S + j + S) * L + fp0]; }
+                        A[(long long)(S + j) * L + fp0] = es_polar_f(pa, pb, tab);
                     }
-                    __syncthreads();
+                    group_sync();
                 }
-                if (p < 4) W.low[p][0] = es_polar_f(A[(long long)(8 + p) * L], A[(long long)(12 + p) * L], tab);
-                __syncthreads();
-                if (p < 2) W.low[4 + p][0] = es_polar_f(W.low[p][0], W.low[p + 2][0], tab);
-                __syncthreads();
-                lam = es_polar_f_sp(W.low[4][0], W.low[5][0], tab, &sp_diff, &sp_sum);
+                for (int j = pl; j < 4; j += LF) W.low[j][fp0] = es_polar_f(A[(long long)(8 + j) * L + fp0], A[(long long)(12 + j) * L + fp0], tab);
+                group_sync();
+                for (int j = pl; j < 2; j += LF) W.low[4 + j][fp0] = es_polar_f(W.low[j][fp0], W.low[j + 2][fp0], tab);
+                group_sync();
+                lam = es_polar_f_sp(W.low[4][fp0], W.low[5][fp0], tab, &sp_diff, &sp_sum);
                 dirty = true;
             } else {
                 const int top = NLEV - __builtin_ctz((unsigned)i);
-                if (top <= 9 && dirty) { __syncthreads(); dirty = false; }      // this step writes slots
+                if (top <= 9 && dirty) { group_sync(); dirty = false; }         // this step writes slots
                 // --- depths top..7: slab to slab, the lane walks the node
                 for (int d = top; d <= 7; ++d) {
                     const int S = N >> d;
@@ -325,29 +407,29 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                 metric = metric + pen;
                 lp_odd = sp_sum;                                      // sibling g = b + a when this bit is 0
             } else {                                                  // fastpolar.py:288-330
-                const bool live = p < cnt;
+                const bool live = pl < cnt;
                 const int nc = 2 * cnt;
                 double k0 = live ? metric + ((pref != 0u) ? lp + al : lp) : __builtin_inf();
                 double k1 = live ? metric + ((pref != 1u) ? lp + al : lp) : __builtin_inf();
-                uint32_t i0 = live ? (uint32_t)(2 * p) : 0xFFFFu, i1 = live ? (uint32_t)(2 * p + 1) : 0xFFFFu;
+                uint32_t i0 = live ? (uint32_t)(2 * pl) : 0xFFFFu, i1 = live ? (uint32_t)(2 * pl + 1) : 0xFFFFu;   // candidate index within the frame
                 // publish what follows a path through the sort
-                const int xb = info_idx & 1;
+                const int xb = (NB == 2) ? (info_idx & 1) : 0;
                 const bool wstart = (info_idx & 31) == 0;
                 W.xpa[xb][p] = pa_;
-                W.xpb[xb][p] = pb_ | ((uint64_t)(wstart ? (uint32_t)p : anc) << 48);
+                W.xpb[xb][p] = pb_ | ((uint64_t)(wstart ? (uint32_t)pl : anc) << 48);
                 W.xb0[xb][p] = b0;
                 W.xhist[xb][p] = wstart ? 0u : hist;
                 if (!(i & 1)) { W.xsp[xb][0][p] = sp_diff; W.xsp[xb][1][p] = sp_sum; }
                 int buf = 0;
-                wide_sort<L>(k0, i0, k1, i1, p, W, buf);
+                wide_sort<L, LF>(k0, i0, k1, i1, p, pl, W, buf);
                 W.skey[buf][2 * p] = k0; W.skey[buf][2 * p + 1] = k1;
                 W.sidx[buf][2 * p] = (uint16_t)i0; W.sidx[buf][2 * p + 1] = (uint16_t)i1;
-                __syncthreads();
-                const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= L: lists of any size run on the next power of two's kernel
-                const int myr = p < keep ? p : 0;                  // dead paths mirror rank 0
-                const uint32_t myc = W.sidx[buf][myr];
-                metric = W.skey[buf][myr];
-                const int parent = (int)(myc >> 1) & (L - 1);
+                if constexpr (WAVE) wave_fence_lds(); else __syncthreads();
+                const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= LF: lists of any size run on the next power of two's kernel
+                const int myr = pl < keep ? pl : 0;                // dead paths mirror rank 0
+                const uint32_t myc = W.sidx[buf][2 * fp0 + myr];
+                metric = W.skey[buf][2 * fp0 + myr];
+                const int parent = fp0 + ((int)(myc >> 1) & (LF - 1));
                 bit = myc & 1u;
                 pa_ = W.xpa[xb][parent];
                 const uint64_t t = W.xpb[xb][parent];
@@ -359,7 +441,8 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                 if ((info_idx & 31) == 31) { TBW[(info_idx >> 5) * L + p] = hist; TBA[(info_idx >> 5) * L + p] = (uint16_t)anc; }
                 cnt = keep;
                 ++info_idx;
-                dirty = false;                                     // every wave passed the sort's barriers after its reads
+                if constexpr (!WAVE) dirty = false;                // every wave passed the sort's barriers after its reads
+                else wave_fence_lds();                             // (one wave: the published rows are rewritten two sorts later, in order)
             }
 
             // --- partial sums: fold upward while the node is a right child (fastpolar.py:156-183); each lane its own path
@@ -390,7 +473,7 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                             }
                         }
                     }
-                    if (dirty) { __syncthreads(); dirty = false; }  // the block about to be rewritten may still be being read
+                    if (dirty) { group_sync(); dirty = false; }     // the block about to be rewritten may still be being read
                     const int Wp = 1 << (t - 5);
                     if (t == 5) beta_st(1, p, cw);
                     else for (int w = 0; w < Wp; ++w) beta_st(Wp + w, p, CB[w * L + p]);
@@ -399,23 +482,23 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
             }
         }
 
-        // ---------------- final ordering (fastpolar.py:335), trace-back, CRC
-        __syncthreads();
-        W.skey[0][p] = metric;
-        __syncthreads();
+        // ---------------- final ordering (fastpolar.py:335), trace-back, CRC -- per frame
+        group_sync();
+        W.skey[0][2 * p] = metric;                                  // (a lane's own sort cells: waves that are groups of their own run out of step)
+        group_sync();
         int rank = 0;
         for (int k = 0; k < cnt; ++k) {
-            const double mk = W.skey[0][k];
-            rank += ((mk < metric) || (mk == metric && k < p)) ? 1 : 0;
+            const double mk = W.skey[0][2 * (fp0 + k)];
+            rank += ((mk < metric) || (mk == metric && k < pl)) ? 1 : 0;
         }
-        if (p < cnt) {
+        if (pl < cnt && f_store) {
             uint8_t* out = a.cand_info + (f * a.lsz + rank) * ES_INFO_BYTES;
-            int curp = p;
+            int curp = pl;
             uint32_t wd[MWIN_W];
             #pragma unroll
             for (int w = MWIN_W - 1; w >= 0; --w) {
-                wd[w] = TBW[w * L + curp];                        // information bits 32w .. 32w+31, first = MSB
-                curp = (int)TBA[w * L + curp];
+                wd[w] = TBW[w * L + fp0 + curp];                  // information bits 32w .. 32w+31, first = MSB
+                curp = (int)TBA[w * L + fp0 + curp] & (LF - 1);
             }
             uint32_t reg = 0;
             #pragma unroll
@@ -429,40 +512,51 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
             a.cand_metric[f * a.lsz + rank] = metric;
             a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == (wd[MWIN_W - 1] & 0xffu));
         }
-        if (p == 0) a.ncand[f] = cnt;
-        __syncthreads();
+        if (pl == 0 && f_store) a.ncand[f] = cnt;
+        group_sync();
     }
+    // ---- release the slot: every wave's slab stores are done (and performed) before the bit clears
+    __threadfence();
+    __syncthreads();
+    if (p == 0) atomicAnd(&a.slot_bits[slot >> 5], ~(1u << (slot & 31)));
 }
 
-template <int L>
+template <int L, int LF>
 int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
 {
-    const size_t lds = sizeof(WideLds<L>);
-    static_assert(sizeof(WideLds<256>) * 3 <= 160 * 1024, "three workgroups per CU at L = 256");
-    if (!(ctx->wide_attr_mask & (unsigned)L)) {      // per context (= per device): the attribute belongs to the device's copy of the kernel
-        ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_scl_wide_kernel<L>),
+    const size_t lds = sizeof(WideLds<L, (LF > 64 ? 2 : 1)>);
+    static_assert((sizeof(WideLds<256, 2>) + 1279) / 1280 * 1280 * 3 <= 160 * 1024, "three workgroups per CU at L = 256 (LDS is handed out in 1 280-byte granules)");
+    static_assert((sizeof(WideLds<64, 1>) + 1279) / 1280 * 1280 * 12 <= 160 * 1024, "twelve one-wave workgroups per CU");
+    static_assert((LF & (LF - 1)) == 0, "power of two");
+    constexpr unsigned attr_bit = (unsigned)LF;                        // one instantiation per list capacity
+    if (!(ctx->wide_attr_mask & attr_bit)) {                           // per context (= per device): the attribute belongs to the device's copy of the kernel
+        ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_scl_wide_kernel<L, LF>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ctx->wide_attr_mask |= (unsigned)L;
+        ctx->wide_attr_mask |= attr_bit;
     }
-    // One slab slot per workgroup.  The slab is sized in units of the context's largest list (Lm); a shorter list gets Lm / L
-    // times as many slots out of the same bytes, so that the chip holds three waves per SIMD at every list size.
-    const int Lm = es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max);
-    long long blocks = B;
-    const long long cap = (long long)ctx->wide_slots * (Lm / L);
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(es_scl_wide_kernel<L>, dim3((unsigned)blocks), dim3(L), lds, st, a);
+    // One slab slot per resident workgroup.  The slab is sized in units of the context's largest block (Lm lanes); a smaller block
+    // gets Lm / L times as many slots out of the same bytes.
+    const int Lm = es_wide_lanes_max(ctx);
+    constexpr int FRB = L / LF;                                     // frames per block
+    const long long blocks = (B + FRB - 1) / FRB;                    // one frame group per wave / block; the hardware keeps <= 3 blocks (L = 128: 5) per CU resident
+    if (blocks >= (1LL << 31)) { ctx->err = "es_scl_batch: batch too large for one launch"; return ES_EINVAL; }
+    a.slot_bits = ctx->d_wide_slot_bits;
+    a.n_slots = ctx->wide_slots * (Lm / L);
+    a.slot_words = (a.n_slots + 31) / 32;
+    hipLaunchKernelGGL((es_scl_wide_kernel<L, LF>), dim3((unsigned)blocks), dim3(L), lds, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
 
 }  // namespace
 
-// Scratch for the wide kernel: per resident workgroup 1024*L doubles + WIDE_AUX_PER_PATH*L bytes.
+// Scratch for this file's kernels: per resident workgroup of Lm lanes 1024*Lm doubles + WIDE_AUX_PER_PATH*Lm bytes.
+// Lists of up to 64 paths run in blocks of 256 lanes, so every context that has the scratch has it for 256-lane blocks.
 size_t es_scl_wide_scratch_bytes(const es_ctx* ctx, int* slots_out)
 {
-    if (ctx->list_size_max <= 32) { *slots_out = 0; return 0; }
-    const size_t Lm = (size_t)(es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max));
-    const int slots = ctx->num_cu * 3 * (int)(256 / Lm);          // twelve waves per CU at the largest list size
+    if (!ctx->wide_enabled) { *slots_out = 0; return 0; }
+    const size_t Lm = (size_t)es_wide_lanes_max(ctx);
+    const int slots = ctx->num_cu * 3 * (int)(256 / Lm);          // twelve waves per CU
     *slots_out = slots;
     return (size_t)slots * (N * Lm * sizeof(double) + (size_t)WIDE_AUX_PER_PATH * Lm);
 }
@@ -471,21 +565,28 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
                        uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
                        uint8_t* cand_ok, int32_t* ncand, hipStream_t st)
 {
-    if (!ctx->d_wide_scratch) { ctx->err = "es_scl_batch: context was created with list_size_max <= 32"; return ES_EINVAL; }
+    if (!ctx->d_wide_scratch) { ctx->err = "es_scl_batch: this context has no scratch for the lane-per-path list decoder (list_size_max <= 32 and scl_lanes 1 never requested before es_reserve)"; return ES_EINVAL; }
     WideArgs a{};
     a.llr = llr; a.is_f64 = (dtype == ES_DTYPE_F64); a.B = B;
     a.frozen = ctx->frozen; a.data_pos = ctx->d_data_pos; a.exp_tab = ctx->d_exp_tab;
-    const size_t Lm = (size_t)(es_list_cap(ctx->list_size_max) < 64 ? 64 : es_list_cap(ctx->list_size_max));
+    const size_t Lm = (size_t)es_wide_lanes_max(ctx);
     a.alpha = reinterpret_cast<double*>(ctx->d_wide_scratch);
     a.aux = reinterpret_cast<unsigned char*>(ctx->d_wide_scratch) + (size_t)ctx->wide_slots * N * Lm * sizeof(double);
     a.hard_info = hard_info; a.hard_ok = hard_ok; a.cand_info = cand_info;
     a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
     a.skip_if_hard_ok = skip_if_hard_ok;
     a.lsz = L;
-    switch (L <= 64 ? 64 : (L <= 128 ? 128 : 256)) {
-        case 64:  return launch_wide<64>(ctx, a, B, st);
-        case 128: return launch_wide<128>(ctx, a, B, st);
-        case 256: return launch_wide<256>(ctx, a, B, st);
-        default: ctx->err = "wide list_size must be 64, 128 or 256"; return ES_EINVAL;
+    int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
+    switch (LP) {
+        case 1:   return launch_wide<64, 1>(ctx, a, B, st);
+        case 2:   return launch_wide<64, 2>(ctx, a, B, st);
+        case 4:   return launch_wide<64, 4>(ctx, a, B, st);
+        case 8:   return launch_wide<64, 8>(ctx, a, B, st);
+        case 16:  return launch_wide<64, 16>(ctx, a, B, st);
+        case 32:  return launch_wide<64, 32>(ctx, a, B, st);
+        case 64:  return launch_wide<64, 64>(ctx, a, B, st);
+        case 128: return launch_wide<128, 128>(ctx, a, B, st);
+        case 256: return launch_wide<256, 256>(ctx, a, B, st);
+        default: ctx->err = "list_size must be in 1..256"; return ES_EINVAL;
     }
 }

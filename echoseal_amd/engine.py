@@ -201,9 +201,12 @@ class RxEngine:
 
     # ------------------------------------------------------------------ soft demod
     def llr(self, y: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *, start: torch.Tensor | None = None,
-            variant: int = 0, want_diag: bool = False):
+            variant: int = 0, want_diag: bool = False, out: torch.Tensor | None = None):
         B, T = y.shape
-        out = torch.empty((B, 1024), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((B, 1024), dtype=torch.float32, device=self.device)
+        elif out.shape != (B, 1024) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [B, 1024] tensor")
         best_s = torch.empty(B, dtype=torch.int32, device=self.device) if want_diag else None
         score = torch.empty((B, 2), dtype=torch.float32, device=self.device) if want_diag else None
         nat.check(self._ctx, self._lib.es_llr_batch(self._ctx, _ptr(y), B, T, _ptr(start), _ptr(band), _ptr(pn_rows),
@@ -457,10 +460,33 @@ class DecodePipeline:
     values are those of decode_batch (same kernels, same order per batch)."""
 
     def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None, lanes: int = 0,
-                 side_stream: bool = True):
+                 side_stream: bool = True, group: int = 0):
         self.eng = eng
         self.list_size = int(list_size)
         dev = eng.device
+        # `group` > 0: the throughput arrangement -- the front ends (band-pass .. demodulator) of `group` consecutive batches
+        # run on `lanes` front streams and write their LLR rows into ONE buffer, and ONE list-decoder launch (on one of
+        # `scl_streams` streams, own context, one lane per path: es_set_option "scl_lanes" = 1) decodes the whole group:
+        # that mapping needs tens of thousands of frames per launch to fill the chip, which a 1 024-frame batch cannot give it.
+        # Per batch the kernels' inputs and results are those of decode_batch; a batch's list-decoder rows are complete when
+        # its group's launch is (GroupTicket.result() / wait / synchronize flush an incomplete group).
+        self.group = max(0, int(group))
+        if self.group:
+            self.lanes = max(1, int(lanes) or 4)
+            nb = max(1, int(scl_streams))
+            # the short front-end kernels get dispatch priority: they must slip in whenever list-decoder waves leave
+            self.lane_streams = [torch.cuda.Stream(dev, priority=-1) for _ in range(self.lanes)]
+            self.lane_engs = [eng] + [RxEngine(dev, list_size_max=8) for _ in range(self.lanes - 1)]
+            self.backs = [torch.cuda.Stream(dev) for _ in range(nb)]
+            self.scl_engs = [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in range(nb)]
+            for e in self.scl_engs:                   # kernel by launch size: a full group runs one lane per path, a lone batch one frame per wave
+                e.set_option("scl_multi", -1); e.set_option("scl_lanes", 0); e.set_option("scl_lane_slab", 1)
+            self.front = self.side = None
+            self._ring: list = [None] * (nb + 1)      # LLR buffers of the groups in flight (+ the one being filled)
+            self._open = None
+            self._k = self._g = 0
+            self._flush_lanes = 0                     # (tests: 1 = one lane per path whatever the group's size)
+            return
         # `lanes` > 0: the other arrangement -- K independent lanes, each one HIP stream (= one hardware queue) with its
         # own context that runs the WHOLE chain of its batches (k, k+K, ...) in order; no cross-stream events at all.
         self.lanes = max(0, int(lanes))
@@ -494,6 +520,8 @@ class DecodePipeline:
         eng = self.eng
         if frames.shape[1] - 62 > eng.FAST_MAX_LAGS:
             raise ValueError("DecodePipeline serves frame-sized records (use RxEngine.decode_batch for long captures)")
+        if self.group:
+            return self._submit_grouped(frames, band, pn_rows, start, xcorr_events, select)
         if self.lanes:
             j = self._k % self.lanes
             self._k += 1
@@ -547,15 +575,118 @@ class DecodePipeline:
         self._inflight.append(done)
         return SyncResult(y, None, thr, peaks, npeaks, flags=flags), llr, scl, done
 
+    # ---- grouped arrangement
+    def _submit_grouped(self, frames, band, pn_rows, start, xcorr_events, select):
+        B = frames.shape[0]
+        g = self._open
+        if g is not None and (g.B != B or g.select != bool(select)):
+            self._flush(g); g = None
+        if g is None:
+            r = self._g % len(self._ring)
+            prev = self._ring[r]
+            if prev is not None and (prev.llr.shape[0] != self.group * B):
+                prev.done.synchronize(); prev = None
+            g = _Group(self, B, bool(select), prev, self.eng.device)
+            self._ring[r] = g
+            self._open = g
+            self._g += 1
+        j = self._k % self.lanes
+        self._k += 1
+        st, e = self.lane_streams[j], self.lane_engs[j]
+        st.wait_stream(torch.cuda.current_stream(self.eng.device))
+        if g.reuse_after is not None:
+            st.wait_event(g.reuse_after)                                      # the buffer's previous group has been decoded
+        slot = g.count
+        rows = g.llr[slot * B:(slot + 1) * B]
+        with torch.cuda.stream(st):
+            y, y32 = e.bpf2(frames, band)
+            if xcorr_events is not None:
+                xcorr_events[0].record()
+            thr, peaks, npeaks, flags = e.sync_fused(y, y32, band)
+            if xcorr_events is not None:
+                xcorr_events[1].record()
+            if isinstance(start, str):
+                start = peaks[:, 0].clamp(min=0).contiguous()
+            e.llr(y, band, pn_rows, start=start, variant=0, out=rows)
+            ready = torch.cuda.Event()
+            ready.record()
+        for t in (frames, band, pn_rows):
+            t.record_stream(st)
+        g.ready.append(ready)
+        g.count += 1
+        ticket = GroupTicket(g, slot)
+        if g.count == self.group:
+            self._flush(g)
+        return SyncResult(y, None, thr, peaks, npeaks, flags=flags), rows, ticket, ticket
+
+    def _flush(self, g) -> None:
+        if g.done is not None:
+            return
+        j = g.index % len(self.backs)
+        back, e = self.backs[j], self.scl_engs[j]
+        for ev in g.ready:
+            back.wait_event(ev)
+        lp = 1
+        while lp < self.list_size:
+            lp <<= 1
+        # one lane per path once the group gives every SIMD a wave (launches of several groups overlap); a lone batch: the library's choice
+        e.set_option("scl_lanes", 1 if (g.count * g.B * lp >= 64 * 1024 or self._flush_lanes == 1) else 0)
+        with torch.cuda.stream(back):
+            g.scl = e.scl(g.llr[:g.count * g.B], list_size=self.list_size, skip_if_hard_ok=True)
+            if g.select:
+                g.selected = e.select(g.scl)
+            g.done = torch.cuda.Event()
+            g.done.record()
+        if self._open is g:
+            self._open = None
+
     @staticmethod
     def wait(result) -> None:
         result[3].synchronize()
 
     def synchronize(self) -> None:
+        if self.group:
+            if self._open is not None:
+                self._flush(self._open)
+            for st in self.lane_streams:
+                st.synchronize()
         if self.front is not None:
             self.front.synchronize(); self.side.synchronize()
         for b in self.backs:
             b.synchronize()
+
+
+class _Group:
+    """Batches that share one list-decoder launch (DecodePipeline, grouped arrangement)."""
+
+    def __init__(self, pipe: DecodePipeline, B: int, select: bool, prev, device):
+        self.pipe, self.B, self.select = pipe, B, select
+        self.index = pipe._g
+        self.llr = prev.llr if prev is not None else torch.empty((pipe.group * B, 1024), dtype=torch.float32, device=device)
+        self.reuse_after = prev.done if prev is not None else None
+        self.ready: list = []
+        self.count = 0
+        self.scl = self.selected = self.done = None
+
+
+class GroupTicket:
+    """A batch's place in its group: `result()` -> SclResult rows of this batch (flushes / waits as needed)."""
+
+    def __init__(self, g: _Group, slot: int):
+        self.g, self.slot = g, slot
+
+    def synchronize(self) -> None:
+        self.g.pipe._flush(self.g)
+        self.g.done.synchronize()
+
+    def result(self) -> SclResult:
+        self.synchronize()
+        lo, hi = self.slot * self.g.B, (self.slot + 1) * self.g.B
+        s = self.g.scl
+        res = SclResult(s.hard_info[lo:hi], s.hard_ok[lo:hi], s.cand_info[lo:hi], s.cand_metric[lo:hi], s.cand_ok[lo:hi], s.ncand[lo:hi])
+        if self.g.selected is not None:
+            res.selected = tuple(t[lo:hi] for t in self.g.selected)
+        return res
 
 
 def select_payload(scl: SclResult, row: int = 0, validator=None):

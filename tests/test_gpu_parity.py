@@ -451,22 +451,31 @@ def test_sync_fast_large_batch_property(engine):
     assert torch.equal(ref.peaks[mask], fast.peaks[mask])
 
 
-@pytest.mark.parametrize("mode", ["front+decoders", "lanes", "lanes, several frames per wave"])
+@pytest.mark.parametrize("mode", ["front+decoders", "lanes", "lanes, several frames per wave", "grouped", "grouped, one lane per path"])
 def test_decode_pipeline_equals_decode_batch(engine, mode):
     """The streaming pipeline returns, for every batch, exactly what decode_batch returns for it -- including when
     different batches are in flight: the round-1 arrangement (front-end stream + two list-decoder streams), the whole-chain
-    lanes that bench.py runs, and those with the multi-frame list decoder forced (its launches share nothing but the GPU)."""
-    from echoseal_amd.engine import DecodePipeline
-    pipe = DecodePipeline(engine, list_size=8) if mode == "front+decoders" else DecodePipeline(engine, list_size=8, lanes=3)
+    lanes, those with the multi-frame list decoder forced (its launches share nothing but the GPU), and the grouped arrangement
+    that bench.py runs (groups of three batches share one list-decoder launch: two full groups and an incomplete one; with the
+    kernel the library picks for so few frames, and with the one-lane-per-path kernel the full-size groups get)."""
+    from echoseal_amd.engine import DecodePipeline, GroupTicket
+    if mode.startswith("grouped"):
+        pipe = DecodePipeline(engine, list_size=8, lanes=2, scl_streams=2, group=3)
+    else:
+        pipe = DecodePipeline(engine, list_size=8) if mode == "front+decoders" else DecodePipeline(engine, list_size=8, lanes=3)
     if mode.endswith("per wave"):
         for e in pipe.scl_engs:
             e.set_option("scl_multi", 1)
+    if mode.endswith("per path"):
+        pipe._flush_lanes = 1
     batches = [_workload(256, noise=n, seed=11 + k, ctr0=1000 * k) for k, n in enumerate((0.0, 0.05, 0.2, 0.0, 0.4, 0.1, 0.0))]
     dev = [_dev(engine, *w) for w in batches]
     out = [pipe.submit(f, b, p, select=(mode != "front+decoders")) for f, b, p in dev]           # all enqueued back to back
     pipe.synchronize()
     engine.set_option("scl_multi", -1)
     for (f, b, p), (sy, llr, scl, done) in zip(dev, out):
+        if isinstance(scl, GroupTicket):
+            scl = scl.result()
         if mode != "front+decoders":
             for u, v in zip(scl.selected, engine.select(scl)):
                 assert torch.equal(u, v)
@@ -581,9 +590,13 @@ def test_scl_multi_frames_per_wave(engine, oracle, L):
             ref = engine.scl(x, list_size=L, skip_if_hard_ok=skip)
             engine.set_option("scl_multi", 1)
             got = engine.scl(x, list_size=L, skip_if_hard_ok=skip)
+            engine.set_option("scl_lanes", 1)                       # one lane per path, 64/L frames per wave (es_scl_wide.hip)
+            got1 = engine.scl(x, list_size=L, skip_if_hard_ok=skip)
+            engine.set_option("scl_lanes", 0)
             engine.set_option("scl_multi", -1)
             for name in ("hard_info", "hard_ok", "ncand", "cand_info", "cand_metric", "cand_ok"):
                 assert torch.equal(getattr(ref, name), getattr(got, name)), (name, L, dtype, skip)
+                assert torch.equal(getattr(ref, name), getattr(got1, name)), (name, L, dtype, skip, "one lane per path")
             assert bool(torch.all(got.hard_ok[torch.from_numpy(hit).to(engine.device)] == 1))
     for i in range(0, B, 41):
         if hit[i]:

@@ -43,11 +43,12 @@ out["c3_launch_fused"]["note"] = "reads also cover the float64 samples of the ex
 json.dump(out, open(os.path.join(DST, "r02_xcorr32_pmc_traffic.json"), "w"), indent=1)
 
 # ---- list decoder (both mappings of the multi-frame kernel)
-sa = counters("scl_a", "es_scl_multi_kernel"); sb = counters("scl_b", "es_scl_multi_kernel")
+sa = counters("scl_a", "es_scl_"); sb = counters("scl_b", "es_scl_")
 scl = {"source": "rocprofv3 --pmc (two passes of 8 SQ/GRBM counters, counters only) -- python3 tools/scl_pmc2.py '' 65536; MI355X, round 2; "
                  "SQ_* cycle counters are in quad-cycles, GRBM_GUI_ACTIVE sums the 8 XCDs"}
 for tag, part, what in (("es_scl_multi_kernel<8>  B=65536, 16 paths x 4 lanes per wave (the mapping of the pipelined headline)", "<8, 4>", "two frames per wave"),
-                        ("es_scl_multi_kernel<8,2 lanes>  B=65536, 32 paths x 2 lanes per wave (batches of tens of thousands of frames)", "<8, 2>", "four frames per wave")):
+                        ("es_scl_multi_kernel<8,2 lanes>  B=65536, 32 paths x 2 lanes per wave", "<8, 2>", "four frames per wave"),
+                        ("es_scl_wide_kernel<64,8>  B=65536, 64 paths x 1 lane per wave (the grouped pipeline of the headline; batches of tens of thousands of frames)", "<64, 8>", "eight frames per wave")):
     g = lambda d, c: pick(d, part, c)
     valu, act = g(sa, "SQ_INSTS_VALU"), g(sa, "SQ_ACTIVE_INST_VALU")
     gui = g(sb, "GRBM_GUI_ACTIVE") / 8.0
