@@ -64,7 +64,7 @@ FP64_ISSUE_PEAK_GWIPS = 256 * 4 * 2.4 / 4.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=480)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frame records per GPU per step (C2 = 1024)")
     ap.add_argument("--list-size", type=int, default=8)
@@ -268,6 +268,10 @@ def run_rank(a) -> None:
     pipe.synchronize()
 
     out_legs = {}
+    # the legs' pipelines run on the headline pipeline's streams: more than GPU_MAX_HW_QUEUES live streams would share hardware queues
+    big_streams = (list(pipe.backs) + list(pipe.lane_streams if a.group or a.lanes else []))[:a.big_lanes]
+    if len(big_streams) < a.big_lanes:
+        big_streams = None
 
     # ============================================================ leg c3 (one GPU): 65 536 jittered / noisy windows
     roof_c3 = roof_fused = None
@@ -326,7 +330,7 @@ def run_rank(a) -> None:
         # the timed c3 leg: the same pass through the lane pipeline -- step k on lane k mod 2, so that the front end of one
         # step runs beside the list decoder of the other (the list decoder's blocks are not persistent: wave slots free up
         # as it proceeds)
-        pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes)
+        pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=big_streams)
         for e in pipe3.lane_engs:                                # kernels by launch size: 65 536 records -> one lane per path
             e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
         def c3_lane_step():
@@ -402,7 +406,7 @@ def run_rank(a) -> None:
         peak4 = torch.empty(n4, dtype=torch.int32, device=dev)
         chunk = max(1, min(a.c4_chunk, n4))
 
-        pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes)
+        pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=big_streams)
         for e in pipe4.lane_engs:
             e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
 

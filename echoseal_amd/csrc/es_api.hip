@@ -393,7 +393,7 @@ int es_set_option(es_ctx* ctx, const char* name, int value)
         return ES_OK;
     }
     if (std::strcmp(name, "scl_lanes") == 0 || std::strcmp(name, "scl_lane_slab") == 0) {
-        const bool slab_only = name[9] == '_';
+        const bool slab_only = std::strcmp(name, "scl_lane_slab") == 0;
         if (slab_only ? (value != 1) : (value != 0 && value != 1 && value != 2 && value != 4))
             return fail(ctx, ES_EINVAL, slab_only ? "es_set_option: scl_lane_slab takes 1" : "es_set_option: scl_lanes takes 0 (by batch size), 1, 2 or 4");
         if (value == 1 && !ctx->d_wide_scratch) {             // one lane per path: the slab of es_scl_wide.hip (allocated here, never in an enqueue call)

@@ -460,7 +460,7 @@ class DecodePipeline:
     values are those of decode_batch (same kernels, same order per batch)."""
 
     def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None, lanes: int = 0,
-                 side_stream: bool = True, group: int = 0):
+                 side_stream: bool = True, group: int = 0, streams=None):
         self.eng = eng
         self.list_size = int(list_size)
         dev = eng.device
@@ -492,7 +492,11 @@ class DecodePipeline:
         self.lanes = max(0, int(lanes))
         if self.lanes:
             # (lane 0 on the caller's own stream was measured slower: 1.29 M against 1.43 M frames/s at 7 lanes)
-            self.lane_streams = [torch.cuda.Stream(dev) for _ in range(self.lanes)]
+            # `streams`: HIP streams to run the lanes on instead of new ones -- a process that builds several pipelines should hand
+            # the same streams to each: beyond GPU_MAX_HW_QUEUES (8) live streams, streams share hardware queues and serialise
+            self.lane_streams = list(streams)[:self.lanes] if streams is not None else [torch.cuda.Stream(dev) for _ in range(self.lanes)]
+            if len(self.lane_streams) != self.lanes:
+                raise ValueError("streams: one per lane")
             self.lane_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in range(self.lanes - 1)]
             self.scl_engs = self.lane_engs
             self.backs = self.lane_streams

@@ -20,4 +20,4 @@ cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 for d in rowcopy_FETCH_SIZE rowcopy_WRITE_SIZE; do python tools/pmc_by_grid.py $OUT/$d rowcopy; python tools/pmc_by_grid.py $OUT/$d copy4; done
 for d in x32_FETCH_SIZE x32_WRITE_SIZE x32_sq; do python tools/pmc_by_grid.py $OUT/$d es_xcorr32; done
-for d in scl_a scl_b; do python tools/pmc_by_grid.py $OUT/$d es_scl_multi; done
+for d in scl_a scl_b; do python tools/pmc_by_grid.py $OUT/$d es_scl_; done
