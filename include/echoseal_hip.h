@@ -207,11 +207,16 @@ int es_resample_batch(es_ctx* ctx, const void* x_dev, int dtype, int64_t B, int6
  * test compare the device arithmetic with the host C library bit for bit.  t_dev, out_dev float64 [n].                   */
 int es_softplus_batch(es_ctx* ctx, const double* t_dev, int64_t n, double* out_dev, void* stream);
 
-/* Tuning knobs; results never depend on them.  "scl_multi": -1 (default) lets es_scl_batch choose between one
- * frame per wavefront and 16/L frames per wavefront (list sizes <= 8; better lane use at the bottom of the LLR
- * tree, wants batches that fill the chip), 0 forces the former, 1 the latter.  "scl_lanes": lanes per path of the latter
- * kernel -- 4 (16 paths per wavefront), 2 (32 paths per wavefront: fewer instructions per frame, longer wavefronts; for
- * batches of tens of thousands of frames) or 0 (default: chosen by batch size).                                     */
+/* Tuning knobs; results never depend on them.  es_scl_batch has three mappings of list paths to lanes for lists of up to
+ * 32 paths: one frame per wavefront (a path owns 64/L lanes: lowest latency, one wavefront per SIMD), several frames per
+ * wavefront (a path owns 4 or 2 lanes: 16 or 32 paths per wavefront, three wavefronts per SIMD), and one lane per path (64/L
+ * frames per wavefront, every lane busy at every tree depth: fewest instructions per frame, but a wavefront carries 64/L
+ * frames through the whole decode, so it wants tens of thousands of frames per launch; the kernel that also serves lists of
+ * 64..256 paths).  "scl_multi": -1 (default) chooses by batch size, 0 forces one frame per wavefront, 1 several.
+ * "scl_lanes": lanes per path of the latter -- 4, 2, 1, or 0 (default: by batch size; 1 only when the context has that
+ * kernel's scratch slab).  "scl_lane_slab" = 1 allocates that slab (1.6 GB; contexts created with list_size_max > 32 have
+ * it from the start) without forcing anything: an allocation, so it belongs next to es_create / es_reserve, never between
+ * enqueue calls that must not synchronise.  "scl_lanes" = 1 allocates it too.                                          */
 int es_set_option(es_ctx* ctx, const char* name, int value);
 
 /* ---- the step after the list decoder ------------------------------------------------
