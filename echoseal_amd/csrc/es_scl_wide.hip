@@ -103,11 +103,110 @@ __device__ __forceinline__ double wxor_f64(double x, int D)
 
 __device__ __forceinline__ bool cand_before(double ka, uint32_t ia, double kb, uint32_t ib) { return (ka < kb) || (ka == kb && ia < ib); }
 
+#ifndef ES_WIDE_SORT_ASM
+#define ES_WIDE_SORT_ASM 1
+#endif
+#if ES_WIDE_SORT_ASM
+// Compare-exchange steps of the sort network, written out: path metrics are sums of non-negative penalties (or +inf for a dead
+// lane), so their bit patterns order like their values and (metric, index) compares as the 96-bit unsigned number hi:lo:index --
+// ONE borrow chain of three subtractions leaves "mine sorts before the partner's" in VCC, and with the partner in a lane that DPP
+// reaches the partner's words are an operand modifier of the subtractions and of the three selects: 6 vector instructions per
+// element and stage where the compiler's rendering of cand_before() + selects takes 10.  With the DPP modifier the subtraction is
+// partner - mine (the modified operand is the minuend; tools/ub/ub_dppvcc.hip), so VCC = "the partner sorts before mine" and keeping
+// mine is VCC xor take_min (equal elements are two dead lanes' identical fillers: either may be kept).  (s_nop 1: a DPP operand must
+// not have been written by the two preceding vector instructions; the compiler cannot see into the block.)  tools/ub/ub_sortce.hip
+// checks every step form against plain C++.
+#define ES_CE_DPP(CTRL, lo, hi, ix, tmask)                                                                                   \
+    do { uint32_t t_;                                                                                                        \
+        asm volatile("s_nop 1\n\t"                                                                                           \
+                     "v_sub_co_u32_dpp %3, vcc, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                              \
+                     "v_subb_co_u32_dpp %3, vcc, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+                     "v_subb_co_u32_dpp %3, vcc, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+                     "s_xor_b64 vcc, vcc, %4\n\t"                                                                            \
+                     "v_cndmask_b32_dpp %2, %2, %2, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                             \
+                     "v_cndmask_b32_dpp %0, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                             \
+                     "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                                 \
+                     : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "s"(tmask) : "vcc");                                        \
+    } while (0)
+// the partner's words already fetched (ds_swizzle / ds_bpermute / LDS): keep mine where (mine < other) == take_min
+__device__ __forceinline__ void ce_pair(uint32_t& lo, uint32_t& hi, uint32_t& ix, uint32_t olo, uint32_t ohi, uint32_t oix, unsigned long long tmask)
+{
+    uint32_t t_;
+    asm volatile("v_sub_co_u32 %3, vcc, %2, %6\n\t"
+                 "v_subb_co_u32 %3, vcc, %0, %4, vcc\n\t"
+                 "v_subb_co_u32 %3, vcc, %1, %5, vcc\n\t"
+                 "s_xnor_b64 vcc, vcc, %7\n\t"
+                 "v_cndmask_b32 %2, %6, %2, vcc\n\t"
+                 "v_cndmask_b32 %0, %4, %0, vcc\n\t"
+                 "v_cndmask_b32 %1, %5, %1, vcc"
+                 : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "v"(olo), "v"(ohi), "v"(oix), "s"(tmask) : "vcc");
+}
+// a lane's own two elements: swap where (element 1 < element 0) == ascending
+__device__ __forceinline__ void ce_inlane(uint32_t& lo0, uint32_t& hi0, uint32_t& ix0, uint32_t& lo1, uint32_t& hi1, uint32_t& ix1, unsigned long long amask)
+{
+    uint32_t t_, nlo0, nhi0, nix0;
+    asm volatile("v_sub_co_u32 %3, vcc, %9, %6\n\t"
+                 "v_subb_co_u32 %3, vcc, %7, %4, vcc\n\t"
+                 "v_subb_co_u32 %3, vcc, %8, %5, vcc\n\t"
+                 "s_xnor_b64 vcc, vcc, %10\n\t"
+                 "v_cndmask_b32 %0, %4, %7, vcc\n\t"
+                 "v_cndmask_b32 %1, %5, %8, vcc\n\t"
+                 "v_cndmask_b32 %2, %6, %9, vcc\n\t"
+                 "v_cndmask_b32 %7, %7, %4, vcc\n\t"
+                 "v_cndmask_b32 %8, %8, %5, vcc\n\t"
+                 "v_cndmask_b32 %9, %9, %6, vcc"
+                 : "=&v"(nlo0), "=&v"(nhi0), "=&v"(nix0), "=&v"(t_), "+v"(lo0), "+v"(hi0), "+v"(ix0), "+v"(lo1), "+v"(hi1), "+v"(ix1)
+                 : "s"(amask) : "vcc");
+    lo0 = nlo0; hi0 = nhi0; ix0 = nix0;
+}
+#endif
+
 // Bitonic network over 2L (key, index) pairs, element e = 2 * lane + b held as (k0, i0) / (k1, i1); ascending on exit.
 // (LF < L: independent networks over aligned groups of LF lanes -- one per frame; pl = lane index within the frame)
 template <int L, int LF>
 __device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, uint32_t& i1, const int p, const int pl, WideLds<L, (LF > 64 ? 2 : 1)>& W, int& buf)
 {
+#if ES_WIDE_SORT_ASM
+    uint64_t u0, u1; __builtin_memcpy(&u0, &k0, 8); __builtin_memcpy(&u1, &k1, 8);
+    uint32_t lo0 = (uint32_t)u0, hi0 = (uint32_t)(u0 >> 32), lo1 = (uint32_t)u1, hi1 = (uint32_t)(u1 >> 32);
+    #pragma unroll
+    for (int k = 2; k <= 2 * LF; k <<= 1) {
+        const bool asc = ((2 * pl) & k) == 0;                    // k == 2 LF: always ascending
+        #pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j == 1) {                                        // partner = the lane's other element
+                ce_inlane(lo0, hi0, i0, lo1, hi1, i1, __builtin_amdgcn_ballot_w64(asc));
+            } else {
+                const int dl = j >> 1;                           // partner lane p ^ dl, same b
+                const unsigned long long tm = __builtin_amdgcn_ballot_w64(((pl & dl) == 0) == asc);     // take the smaller of the pair
+                if (dl == 1) { ES_CE_DPP("quad_perm:[1,0,3,2]", lo0, hi0, i0, tm); ES_CE_DPP("quad_perm:[1,0,3,2]", lo1, hi1, i1, tm); }
+                else if (dl == 2) { ES_CE_DPP("quad_perm:[2,3,0,1]", lo0, hi0, i0, tm); ES_CE_DPP("quad_perm:[2,3,0,1]", lo1, hi1, i1, tm); }
+                else if (dl == 8) { ES_CE_DPP("row_ror:8", lo0, hi0, i0, tm); ES_CE_DPP("row_ror:8", lo1, hi1, i1, tm); }
+                else {
+                    uint32_t a0, b0, c0, a1, b1, c1;
+                    if (dl >= 64) {
+                        W.skey[buf][2 * p] = __builtin_bit_cast(double, ((uint64_t)hi0 << 32) | lo0);
+                        W.skey[buf][2 * p + 1] = __builtin_bit_cast(double, ((uint64_t)hi1 << 32) | lo1);
+                        W.sidx[buf][2 * p] = (uint16_t)i0; W.sidx[buf][2 * p + 1] = (uint16_t)i1;
+                        __syncthreads();
+                        const int o = p ^ dl;
+                        const uint64_t x0 = __builtin_bit_cast(uint64_t, W.skey[buf][2 * o]), x1 = __builtin_bit_cast(uint64_t, W.skey[buf][2 * o + 1]);
+                        a0 = (uint32_t)x0; b0 = (uint32_t)(x0 >> 32); a1 = (uint32_t)x1; b1 = (uint32_t)(x1 >> 32);
+                        c0 = W.sidx[buf][2 * o]; c1 = W.sidx[buf][2 * o + 1];
+                        buf ^= 1;
+                    } else {
+                        a0 = (uint32_t)wxor_b32((int)lo0, dl); b0 = (uint32_t)wxor_b32((int)hi0, dl); c0 = (uint32_t)wxor_b32((int)i0, dl);
+                        a1 = (uint32_t)wxor_b32((int)lo1, dl); b1 = (uint32_t)wxor_b32((int)hi1, dl); c1 = (uint32_t)wxor_b32((int)i1, dl);
+                    }
+                    ce_pair(lo0, hi0, i0, a0, b0, c0, tm);
+                    ce_pair(lo1, hi1, i1, a1, b1, c1, tm);
+                }
+            }
+        }
+    }
+    u0 = ((uint64_t)hi0 << 32) | lo0; u1 = ((uint64_t)hi1 << 32) | lo1;
+    __builtin_memcpy(&k0, &u0, 8); __builtin_memcpy(&k1, &u1, 8);
+#else
     #pragma unroll
     for (int k = 2; k <= 2 * LF; k <<= 1) {
         const bool asc = ((2 * pl) & k) == 0;                    // k == 2 LF: always ascending
@@ -140,6 +239,7 @@ __device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, 
             }
         }
     }
+#endif
 }
 
 // hard decision -> butterfly -> data bits -> CRC of one frame by one wave (fastpolar.py:260-268); returns the CRC verdict to every lane
