@@ -21,9 +21,9 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     q = rng.choice([-12.0, -6.0, -3.0, 0.0, 3.0, 6.0, 12.0], size=(B, 1024), p=[.1, .15, .2, .1, .2, .15, .1]).astype(np.float32)
     q[: B // 2] += rng.choice([0.0, 0.5], size=(B // 2, 1024)).astype(np.float32)
     x = torch.from_numpy(q).to(dev)
-    for L in (1, 2, 4, 8, 16, int(rng.choice([3, 5, 6, 7, 11, 13]))):
+    for L in (1, 2, 4, 8, 16, 32, int(rng.choice([3, 5, 6, 7, 11, 13, 24, 29]))):
         eng.set_option("scl_multi", 0); a = eng.scl(x, list_size=L, skip_if_hard_ok=False)
-        for lanes in (4, 2):                         # the two mappings of the multi-frame kernel against the one-frame kernel
+        for lanes in (4, 2, 1):                      # the mappings of the several-frames-per-wave kernels (1: one lane per path, es_scl_wide.hip) against the one-frame kernel
             eng.set_option("scl_multi", 1); eng.set_option("scl_lanes", lanes); b = eng.scl(x, list_size=L, skip_if_hard_ok=False)
             eng.set_option("scl_multi", -1); eng.set_option("scl_lanes", 0)
             for nm in ("hard_info", "hard_ok", "ncand", "cand_info", "cand_metric", "cand_ok"):
