@@ -8,7 +8,9 @@ DST = os.path.join(ROOT, "profiles")
 
 def counters(sub, pat):
     d = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = sorted(files, key=os.path.getmtime)[-1:]          # gpurun merges into gpurun_out/: files of earlier collections stay behind
+    for f in files:
         for r in csv.DictReader(open(f)):
             if pat in r["Kernel_Name"]:
                 d[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -65,7 +67,7 @@ for tag, part, what in (("es_scl_multi_kernel<8>  B=65536, 16 paths x 4 lanes pe
                    "this mix), so the issue peak is one wave-instruction per 4 cycles and SIMD"}
 json.dump(scl, open(os.path.join(DST, "r02_scl_pmc.json"), "w"), indent=1)
 
-for f in glob.glob(os.path.join(SRC, "bench_stats", "**", "*kernel_stats.csv"), recursive=True):
+for f in sorted(glob.glob(os.path.join(SRC, "bench_stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:
     shutil.copy(f, os.path.join(DST, "r02_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, "r02_bench.json"))
 print(json.dumps(out, indent=1)[:1500]); print(json.dumps(scl, indent=1)[:1800])
