@@ -35,6 +35,9 @@
 //
 // Values are bit-identical to the reference list decoder for the same reason as in es_scl.hip (es_math.h).
 #include "es_scl_common.h"
+#ifndef ES_WIDE_GBATCH
+#define ES_WIDE_GBATCH 8                          /* load pairs in flight in the lane-serial g loops (divides 8; 8: +1 % over 4, measured) */
+#endif
 #ifndef ES_WIDE_PREFETCH
 #define ES_WIDE_PREFETCH 2                        /* parent pairs loaded ahead in the lane-serial f loops (2: +2.4 % over 1 at L = 8, measured) */
 #endif
@@ -439,12 +442,12 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                             uint32_t wbits; int nb;
                             if (S >= 32) { wbits = beta_ld((S + j0) >> 5, bs); nb = 32; }
                             else { wbits = b0 >> S; nb = S; }
-                            for (int u = 0; u < nb; u += 4) {                      // four independent load pairs in flight
-                                double xa[4], xb[4];
+                            for (int u = 0; u < nb; u += ES_WIDE_GBATCH) {         // (g is an add: the loop is memory latency) GBATCH independent load pairs in flight
+                                double xa[ES_WIDE_GBATCH], xb[ES_WIDE_GBATCH];
                                 #pragma unroll
-                                for (int v = 0; v < 4; ++v) ld_pair(j0 + u + v, xa[v], xb[v]);
+                                for (int v = 0; v < ES_WIDE_GBATCH; ++v) ld_pair(j0 + u + v, xa[v], xb[v]);
                                 #pragma unroll
-                                for (int v = 0; v < 4; ++v) dst[(long long)(j0 + u + v) * L] = es_polar_g(xa[v], xb[v], (wbits >> (u + v)) & 1u);
+                                for (int v = 0; v < ES_WIDE_GBATCH; ++v) dst[(long long)(j0 + u + v) * L] = es_polar_g(xa[v], xb[v], (wbits >> (u + v)) & 1u);
                             }
                         }
                     } else {
