@@ -104,8 +104,8 @@ class WatermarkDetector:
         and the evolution of `session_nonce` are those of calling the reference's verify() on the clips one after the other
         (rtwm/detector.py:44-53, 105-152); what is batched is the GPU work.  Per group of equally long clips: ONE sync launch
         sequence over (clips x 4 bands) records and ONE header decode over every peak that can hold a frame; then, clip
-        by clip and band by band in the reference's order, ONE demodulate + list-decode + validate batch over all
-        (peak, counter) candidates of the band, walked on the host with the reference's early return."""
+        by clip, ONE demodulate + list-decode + validate batch over the (peak, counter) candidates of all four bands, walked on the
+        host band by band in the reference's order with its early return."""
         fs_list = list(fs_in) if isinstance(fs_in, (list, tuple)) else [fs_in] * len(clips)
         signals = [np.asarray(self._conditioned(c, f)).reshape(-1) for c, f in zip(clips, fs_list)]
         signals = [sg if sg.dtype == np.int16 else sg.astype(np.float32, copy=False) for sg in signals]
@@ -123,10 +123,7 @@ class WatermarkDetector:
         for i in range(len(signals)):
             ok = False
             if scans[i] is not None:
-                for bi in range(len(order)):
-                    if self._scan_decide(scans[i], bi):
-                        ok = True
-                        break
+                ok = self._scan_decide_all(scans[i])
             out.append(ok)
         return out
 
@@ -158,11 +155,12 @@ class WatermarkDetector:
         return [{"bands": bands, "frames": frames, "rows": rows_a - c * nb, "sel": np.flatnonzero((rows_a // nb) == c) if rows else np.zeros(0, np.int64),
                  "starts": np.array(starts, np.int64), "hdr": hdr} for c in range(g)]
 
-    def _scan_decide(self, scan, bi: int) -> bool:
-        """The per-band loop of _scan_band_multi_frame (rtwm/detector.py:105-152) over prepared peaks / headers."""
+    def _scan_plan(self, scan, bi: int):
+        """The candidate (peak, counter) pairs of one band in the reference's try order (rtwm/detector.py:105-140):
+        -> (plan [(peak slot j, start, ctr)], header log of the peaks looked at)."""
         band = scan["bands"][bi]
         sel = [int(j) for j in scan["sel"] if scan["rows"][j] == bi]       # this band's peaks, in peak order
-        plan: list[tuple[int, int, int]] = []                               # (peak slot j, start, ctr) in the reference's try order
+        plan: list[tuple[int, int, int]] = []
         hdr_log = []
         tried = 0
         for j in sel:
@@ -188,16 +186,42 @@ class WatermarkDetector:
             for ctr in cands[:MAX_TRIES - tried]:
                 plan.append((j, start, ctr))
             tried += len(cands[:MAX_TRIES - tried])
+        return plan, hdr_log
+
+    def _scan_replay(self, scan, bi: int, plan, hdr_log, results) -> bool:
+        """Walk one band's decoded candidates as the reference does (early return, traces, nonce bookkeeping in _accept)."""
+        band = scan["bands"][bi]
         if self._hdr_trace is not None:
             self._hdr_trace.extend(hdr_log)
-        if not plan:
-            return False
-        results = self._decode_pairs(scan["frames"], [p[0] for p in plan], [p[2] for p in plan])
         for (j, start, ctr), blobs in zip(plan, results):
             if self._trace is not None:
                 self._trace.append((int(band[0]), int(start), int(ctr)))
             if self._accept(blobs, ctr):
                 return True
+        return False
+
+    def _scan_decide(self, scan, bi: int) -> bool:
+        """The per-band loop of _scan_band_multi_frame (rtwm/detector.py:105-152) over prepared peaks / headers."""
+        plan, hdr_log = self._scan_plan(scan, bi)
+        if not plan:
+            if self._hdr_trace is not None:
+                self._hdr_trace.extend(hdr_log)
+            return False
+        results = self._decode_pairs(scan["frames"], [p[0] for p in plan], [p[2] for p in plan])
+        return self._scan_replay(scan, bi, plan, hdr_log, results)
+
+    def _scan_decide_all(self, scan) -> bool:
+        """All bands of one clip: the candidates of every band go through ONE demodulate + list-decode + validate batch (decoding
+        is stateless; a band the reference would not have reached costs GPU time, never a different answer), then the bands
+        are walked in the reference's order with its early return -- results, traces and nonce bookkeeping as band by band."""
+        plans = [self._scan_plan(scan, bi) for bi in range(len(scan["bands"]))]
+        flat = [p for plan, _ in plans for p in plan]
+        results = self._decode_pairs(scan["frames"], [p[0] for p in flat], [p[2] for p in flat]) if flat else []
+        at = 0
+        for bi, (plan, hdr_log) in enumerate(plans):
+            if self._scan_replay(scan, bi, plan, hdr_log, results[at:at + len(plan)]):
+                return True
+            at += len(plan)
         return False
 
     def verify_raw_frame(self, signal: np.ndarray) -> bool:
