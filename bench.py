@@ -12,9 +12,14 @@ already resident in HBM: band-pass + 63-chip NCC + median/MAD threshold + NMS ->
 counter) -> Polar(1024,448) SCL-8 (validator None).  Workload = BASELINE config 2 (C2): 1 024 clean 1215-sample
 float32 frames per GPU, key 0xAA*32, ctr = i, payload RNG seed 20260101; for N > 1 every rank decodes its own
 1 024-frame shard of the counter range [0, 1024 N) (weak scaling); rank 0 derives the key/PN schedule and broadcasts
-it once over RCCL before the timed region; the data path has no collective.
+it once over RCCL before the timed region; the data path has no collective.  Steps are streamed through
+echoseal_amd.engine.DecodePipeline: by default its grouped arrangement (--group 16: the front ends of 16 consecutive batches
+on four HIP streams fill one LLR buffer and ONE list-decoder launch -- one lane per path, eight frames per wave -- decodes
+the group; the last, possibly incomplete, group is decoded inside the timed region), or --group 0: seven whole-chain lanes.
 
 Further driver-timed legs in the same JSON line (`legs`), each bracketed by barrier + synchronize like the headline:
+  c2_lanes  the headline's batches through the other arrangement (seven whole-chain lanes, one list-decoder launch per batch):
+       the latency-oriented side of the trade, so that the line carries both.
   c3   BASELINE config 3 on one GPU: 65 536 windows of 2 048 samples (frame resampled +-5 %, random offset, AWGN at
        -15 dB), end to end: band-pass -> fused sync (float32 correlation row in LDS + exact threshold / peaks, one kernel) ->
        _llr at the DETECTED peak -> SCL-8 -> selection.
@@ -47,8 +52,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The streaming pipeline keeps 7 batches in flight on 7 HIP streams; the HIP runtime multiplexes streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  Must be set before HIP starts.
+# The streaming pipeline runs on 6-7 HIP streams; the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4), and streams that share a queue serialise.  Must be set before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 KEY = b"\xAA" * 32
@@ -205,7 +210,7 @@ def run_rank(a) -> None:
     from echoseal_amd.engine import DecodePipeline, RxEngine
     from echoseal_amd import workloads as WL
 
-    legs = {"auto": ["c3", "c4", "c5"] if world == 1 else ["c3", "c4"], "none": []}.get(a.legs, a.legs.split(","))
+    legs = {"auto": ["c2_lanes", "c3", "c4", "c5"] if world == 1 else ["c3", "c4"], "none": []}.get(a.legs, a.legs.split(","))
     L = a.list_size
     eng = RxEngine(local, list_size_max=max(16, L))
 
@@ -272,6 +277,31 @@ def run_rank(a) -> None:
     big_streams = (list(pipe.backs) + list(pipe.lane_streams if a.group or a.lanes else []))[:a.big_lanes]
     if len(big_streams) < a.big_lanes:
         big_streams = None
+
+    # ============================================================ leg c2_lanes: the headline's batches through the OTHER arrangement
+    if "c2_lanes" in legs and a.group:
+        # seven whole-chain lanes (no grouping: every batch has its own list-decoder launch, rows within ~3 ms of submission):
+        # the latency-oriented arrangement, timed on the same frames so that the line carries both sides of the trade
+        st7 = (list(pipe.lane_streams) + list(pipe.backs))[:7]
+        st7 += [torch.cuda.Stream(dev) for _ in range(7 - len(st7))]
+        pipe7 = DecodePipeline(eng, list_size=L, lanes=7, streams=st7)
+        for e in pipe7.scl_engs:
+            e.set_option("scl_multi", 1); e.set_option("scl_lanes", 4)
+        n7 = min(a.steps, 200)
+        for _ in range(a.warmup):
+            pipe7.submit(frames_d, band_d, pn_d)
+        pipe7.synchronize(); barrier()
+        t7 = time.perf_counter()
+        for _ in range(n7):
+            _sy7, _l7, res7, _d7 = pipe7.submit(frames_d, band_d, pn_d)
+        pipe7.synchronize(); barrier()
+        dt7 = max_over_ranks(time.perf_counter() - t7)
+        out_legs["c2_lanes"] = {"workload": "C2 (the headline's batches) through seven whole-chain lanes instead of the grouped pipeline: one list-decoder launch "
+                                            "(several frames per wave, four lanes per path) per 1 024-frame batch",
+                                "value": total * n7 / dt7, "unit": "frames/s", "scaling": "weak", "steps": n7, "ms_per_step": 1e3 * dt7 / n7,
+                                "frames_through_list_decoder": int((res7.ncand > 0).sum().item())}
+        eng.set_option("scl_multi", -1); eng.set_option("scl_lanes", 0)
+        del pipe7, res7
 
     # ============================================================ leg c3 (one GPU): 65 536 jittered / noisy windows
     roof_c3 = roof_fused = None
