@@ -554,8 +554,10 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
         if (q == 0 && pl == 0 && f_store) a.ncand[f] = cnt;
         wave_fence_lds();
     }
-    // ---- release the slot: every wave's slab stores are done (and performed) before the bit clears
-    __threadfence();
+    // ---- release the slot: every wave's slab stores are done (and performed) before the bit clears.  The fence is agent-scope: on a
+    // chip whose XCDs have their own L2 it also writes this XCD's dirty slab lines back, so a late eviction here cannot overwrite
+    // what the slot's next owner -- possibly on another XCD -- has written since (an owner only ever reads what it wrote itself).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // (release only: an acquire would also invalidate this XCD's L2 under the blocks still running)
     __syncthreads();
     if (threadIdx.x == 0) atomicAnd(&a.slot_bits[slot >> 5], ~(1u << (slot & 31)));
 }

@@ -632,8 +632,10 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
         if (pl == 0 && f_store) a.ncand[f] = cnt;
         group_sync();
     }
-    // ---- release the slot: every wave's slab stores are done (and performed) before the bit clears
-    __threadfence();
+    // ---- release the slot: every wave's slab stores are done (and performed) before the bit clears.  The fence is agent-scope: on a
+    // chip whose XCDs have their own L2 it also writes this XCD's dirty slab lines back, so a late eviction here cannot overwrite
+    // what the slot's next owner -- possibly on another XCD -- has written since (an owner only ever reads what it wrote itself).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // (release only: an acquire would also invalidate this XCD's L2 under the blocks still running)
     __syncthreads();
     if (p == 0) atomicAnd(&a.slot_bits[slot >> 5], ~(1u << (slot & 31)));
 }
