@@ -1,8 +1,8 @@
-// es_scl_wide.hip -- SCL decoder for LARGE lists (L = 64, 128, 256), one workgroup per frame,
-// one LANE per path.  Same arithmetic and the same bookkeeping idea as es_scl.hip (per-depth slot
-// pointers instead of path copies, trace-back instead of per-path bit arrays, Python's stable sort
-// order), but with L > 32 a frame no longer fits one wavefront.  The detector's default list size is
-// 256 (rtwm/detector.py:27); this kernel is what lets WatermarkDetector(key).verify(...) run unchanged.
+// es_scl_wide.hip -- successive-cancellation LIST decoder with ONE LANE PER PATH: lists of 64, 128 and 256 paths (one frame
+// per block of L lanes; the detector's default list size is 256, rtwm/detector.py:27 -- this kernel is what lets
+// WatermarkDetector(key).verify(...) run unchanged), and shorter lists as 64/L whole frames per one-wave block -- the
+// throughput mapping of large launches.  Same arithmetic and the same bookkeeping idea as es_scl.hip (per-depth slot
+// pointers instead of path copies, trace-back instead of per-path bit arrays, Python's stable sort order).
 //
 // Where things live (lane p owns path p and slot p of every slot-indexed store):
 //   * LLR tree depths 1..7 (512..8 values per path): an L2 / Infinity-Cache resident scratch slab laid out
@@ -27,11 +27,13 @@
 // and only when no sort has happened since those reads (`dirty`).  A depth-by-depth barrier is not needed: within a
 // step a path reads what it has itself just written.
 //
-// The same kernel serves SHORT lists (LF = 1..64 paths per frame) as `lane per path, several frames per wave`: a block of
-// 256 lanes then carries 256/LF frames, every wave is its own group (64/LF whole frames, the sort network stops at the
-// frame's 2*LF candidates, every "barrier" is a wave fence) -- all 64 lanes are busy at every tree depth, which the
-// lanes-share-a-path kernels (es_scl.hip, es_scl_multi.hip) cannot offer at the bottom of the tree.  The price is latency: a
-// wave carries 64/LF frames through the whole decode, so this mapping is for large batches (es_set_option "scl_lanes" = 1).
+// SHORT lists (LF = 1..64 paths per frame): the block is one wave that carries 64/LF whole frames (8 at LF = 8); the sort network
+// stops at the frame's 2 LF candidates and every "barrier" is a wave fence.  All 64 lanes are busy at every tree depth, which the
+// lanes-share-a-path kernels (es_scl.hip, es_scl_multi.hip) cannot offer at the bottom of the tree: 155 k instead of 184 k / 224 k
+// vector instructions per frame at L = 8.  The price is latency: a wave carries its frames through the whole decode (~7 ms), so
+// es_scl_batch picks this mapping for large launches only (or es_set_option "scl_lanes" = 1: the grouped pipeline).
+//
+// Blocks are not persistent: a block decodes its frames and leaves; its slab slot comes from a bitmap (as in es_scl_multi.hip).
 //
 // Values are bit-identical to the reference list decoder for the same reason as in es_scl.hip (es_math.h).
 #include "es_scl_common.h"
@@ -294,7 +296,6 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
 {
     constexpr bool WAVE = (LF <= 64);                // the block is one wave
     constexpr int FRG = L / LF;                      // frames per block
-    constexpr int NG = 1;
     constexpr int NB = WAVE ? 1 : 2;
     static_assert(LF >= 1 && LF <= L && (L % 64) == 0 && L <= 256 && (WAVE ? L == 64 : L == LF), "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -303,7 +304,6 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
     const int lane = p & 63, wv = p >> 6;
     const int pl = p % LF;                           // path within its frame
     const int fp0 = p - pl;                          // slot of the frame's path 0
-    const int gi = 0;
     for (int i = p; i < ES_EXP_TAB_WORDS; i += L) W.exp_tab[i] = a.exp_tab[i];
     __syncthreads();
     auto group_sync = [&]() { if constexpr (WAVE) wave_fence_global(); else __syncthreads(); };
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
     uint32_t* const hd_words = reinterpret_cast<uint32_t*>(&W.skey[0][0]);                  // 32 words ...
     uint8_t* const hd_bytes = reinterpret_cast<uint8_t*>(&W.skey[0][16]);                   // ... and 56 bytes of the hard decision (first wave)
     const long long n_groups = (a.B + FRG - 1) / FRG;
-    for (long long g = (long long)blockIdx.x * NG + gi; g < n_groups; g += (long long)gridDim.x * NG) {      // one group per wave / block (grid = groups)
+    for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {      // one group of FRG frames per block (grid = groups)
         const long long f_raw = g * FRG + (WAVE ? lane / LF : 0);
         const bool f_valid = f_raw < a.B;
         const long long f = f_valid ? f_raw : a.B - 1;          // a missing frame mirrors the last one (never stored)
