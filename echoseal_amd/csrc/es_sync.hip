@@ -312,17 +312,18 @@ __device__ __forceinline__ double key_f64(uint64_t k)
 }
 
 // k-th smallest (0-based) of v[i] (ABSDEV: |v[i] - center|).  All threads return the value.
-template <bool ABSDEV>
+// (NT threads per block: 256, or 1024 for rows that do not fit LDS -- a 5 s recording is 240 000 lags per band)
+template <bool ABSDEV, int NT>
 __device__ double block_select(const double* v, int n, int k, double center,
                                uint32_t* s_hist, uint64_t* s_pref, int* s_k)
 {
     uint64_t prefix = 0;
     int kk = k;
     for (int shift = 56; shift >= 0; shift -= 8) {
-        s_hist[threadIdx.x] = 0;
+        if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t himask = (shift == 56) ? 0ULL : (~0ULL << (shift + 8));
-        for (int i = threadIdx.x; i < n; i += PK_THREADS) {
+        for (int i = threadIdx.x; i < n; i += NT) {
             double x = v[i];
             if (ABSDEV) x = __builtin_fabs(x - center);
             const uint64_t key = f64_key(x);
@@ -330,9 +331,10 @@ __device__ double block_select(const double* v, int n, int k, double center,
         }
         __syncthreads();
         {
-            // exclusive prefix over the 256 digit bins: wave scan + 4 wave totals
+            // exclusive prefix over the 256 digit bins: wave scan + 4 wave totals (the first four waves; barriers by all)
             const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-            const uint32_t h = s_hist[threadIdx.x];
+            const bool bin = threadIdx.x < 256;
+            const uint32_t h = bin ? s_hist[threadIdx.x] : 0u;
             uint32_t incl = h;
             #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -340,13 +342,13 @@ __device__ double block_select(const double* v, int n, int k, double center,
                 if (lane >= o) incl += up;
             }
             __syncthreads();
-            if (lane == 63) s_hist[wv] = incl;            // reuse bins 0..3 as wave totals
+            if (bin && lane == 63) s_hist[wv] = incl;     // reuse bins 0..3 as wave totals
             __syncthreads();
             uint32_t basec = 0;
-            for (int w = 0; w < wv; ++w) basec += s_hist[w];
+            for (int w = 0; w < wv && w < 4; ++w) basec += s_hist[w];
             incl += basec;
             const uint32_t excl = incl - h;
-            if ((int)excl <= kk && kk < (int)incl) {
+            if (bin && (int)excl <= kk && kk < (int)incl) {
                 *s_k = kk - (int)excl;
                 *s_pref = prefix | ((uint64_t)threadIdx.x << shift);
             }
@@ -359,18 +361,18 @@ __device__ double block_select(const double* v, int n, int k, double center,
     return key_f64(prefix);
 }
 
-template <bool ABSDEV>
+template <bool ABSDEV, int NT>
 __device__ double block_median(const double* v, int n, double center, uint32_t* s_hist,
                                uint64_t* s_pref, int* s_k)
 {
-    if (n & 1) return block_select<ABSDEV>(v, n, n / 2, center, s_hist, s_pref, s_k);
-    const double lo = block_select<ABSDEV>(v, n, n / 2 - 1, center, s_hist, s_pref, s_k);
-    const double hi = block_select<ABSDEV>(v, n, n / 2, center, s_hist, s_pref, s_k);
+    if (n & 1) return block_select<ABSDEV, NT>(v, n, n / 2, center, s_hist, s_pref, s_k);
+    const double lo = block_select<ABSDEV, NT>(v, n, n / 2 - 1, center, s_hist, s_pref, s_k);
+    const double hi = block_select<ABSDEV, NT>(v, n, n / 2, center, s_hist, s_pref, s_k);
     return (lo + hi) / 2.0;
 }
 
-template <bool IN_LDS>
-__global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __restrict__ corr, long long B,
+template <bool IN_LDS, int NT>
+__global__ __launch_bounds__(NT) void es_pick_kernel(const double* __restrict__ corr, long long B,
         int n, double* __restrict__ thr_out, int32_t* __restrict__ peaks, int32_t* __restrict__ npeaks,
         const uint8_t* __restrict__ only_flagged, const int* __restrict__ nflag)
 {
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
     __shared__ uint32_t s_hist[256];
     __shared__ uint64_t s_pref;
     __shared__ int s_k;
-    __shared__ double s_bv[PK_THREADS];
-    __shared__ int s_bi[PK_THREADS];
+    __shared__ double s_bv[NT];
+    __shared__ int s_bi[NT];
     __shared__ int s_taken[5];
     __shared__ int s_flag;
     __shared__ uint32_t s_cnt;
@@ -391,21 +393,21 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
         const double* cg = corr + rec * n;
         const double* c = cg;
         if (IN_LDS) {
-            for (int i = threadIdx.x; i < n; i += PK_THREADS) s_row[i] = cg[i];
+            for (int i = threadIdx.x; i < n; i += NT) s_row[i] = cg[i];
             c = s_row;
         }
         __syncthreads();
-        const double med = block_median<false>(c, n, 0.0, s_hist, &s_pref, &s_k);
-        const double mad = block_median<true>(c, n, med, s_hist, &s_pref, &s_k) + 1e-12;
+        const double med = block_median<false, NT>(c, n, 0.0, s_hist, &s_pref, &s_k);
+        const double mad = block_median<true, NT>(c, n, med, s_hist, &s_pref, &s_k) + 1e-12;
         double thr = med + 4.5 * 1.4826 * mad;
         if (0.95 < thr) thr = 0.95;
 
         // ascending scan over lags >= thr; each candidate is checked by the whole block
         int total = 0;
-        for (int base = 0; base < n; base += PK_THREADS) {
+        for (int base = 0; base < n; base += NT) {
             const int i = base + threadIdx.x;
             const bool cand = (i < n) && !(c[i] < thr);
-            unsigned long long mask[PK_THREADS / 64];
+            unsigned long long mask[NT / 64];
             if (threadIdx.x == 0) s_cnt = 0;
             __syncthreads();
             const unsigned long long bal = __ballot(cand);
@@ -413,9 +415,9 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
             __syncthreads();
             if (s_cnt == 0) continue;                  // no candidate among these 256 lags (uniform)
             #pragma unroll
-            for (int w = 0; w < PK_THREADS / 64; ++w) mask[w] = ((unsigned long long*)s_bv)[w];
+            for (int w = 0; w < NT / 64; ++w) mask[w] = ((unsigned long long*)s_bv)[w];
             __syncthreads();
-            for (int w = 0; w < PK_THREADS / 64; ++w) {
+            for (int w = 0; w < NT / 64; ++w) {
                 unsigned long long m = mask[w];
                 while (m) {                            // uniform across the block
                     const int bit = __ffsll((long long)m) - 1;
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
                     int lo = ci - min_distance; if (lo < 0) lo = 0;
                     int hi = ci + min_distance + 1; if (hi > n) hi = n;
                     int bigger = 0;
-                    for (int j = lo + threadIdx.x; j < hi; j += PK_THREADS) bigger |= (c[j] > cv);
+                    for (int j = lo + threadIdx.x; j < hi; j += NT) bigger |= (c[j] > cv);
                     if (__syncthreads_or(bigger) == 0) {
                         if (threadIdx.x == 0 && total < ES_MAX_PEAKS) peaks[rec * ES_MAX_PEAKS + total] = ci;
                         ++total;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
             const int kmax = n < 5 ? n : 5;
             for (int r = 0; r < kmax; ++r) {
                 double bv = 0.0; int bidx = -1;
-                for (int i = threadIdx.x; i < n; i += PK_THREADS) {
+                for (int i = threadIdx.x; i < n; i += NT) {
                     bool used = false;
                     for (int qd = 0; qd < r; ++qd) used |= (s_taken[qd] == i);
                     if (used) continue;
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(PK_THREADS) void es_pick_kernel(const double* __res
                 }
                 s_bv[threadIdx.x] = bv; s_bi[threadIdx.x] = bidx;
                 __syncthreads();
-                for (int sft = PK_THREADS / 2; sft > 0; sft >>= 1) {
+                for (int sft = NT / 2; sft > 0; sft >>= 1) {
                     if (threadIdx.x < sft) {
                         const double ov = s_bv[threadIdx.x + sft]; const int oi = s_bi[threadIdx.x + sft];
                         const double mv = s_bv[threadIdx.x]; const int mi = s_bi[threadIdx.x];
@@ -536,10 +538,10 @@ int es_launch_pick_flagged(es_ctx* ctx, const double* corr, int64_t B, int n_lag
     const long long cap = (long long)ctx->num_cu * (nflag ? 2 : 16);
     if (blocks > cap) blocks = cap;
     if (n_lags <= PK_LDS_N)
-        hipLaunchKernelGGL(es_pick_kernel<true>, dim3((unsigned)blocks), dim3(PK_THREADS), 0, st, corr,
+        hipLaunchKernelGGL((es_pick_kernel<true, PK_THREADS>), dim3((unsigned)blocks), dim3(PK_THREADS), 0, st, corr,
                            (long long)B, n_lags, thr, peaks, npeaks, flags, nflag);
-    else
-        hipLaunchKernelGGL(es_pick_kernel<false>, dim3((unsigned)blocks), dim3(PK_THREADS), 0, st, corr,
+    else                                              // long rows (recordings): one block per row, so make it a big one
+        hipLaunchKernelGGL((es_pick_kernel<false, 1024>), dim3((unsigned)blocks), dim3(1024), 0, st, corr,
                            (long long)B, n_lags, thr, peaks, npeaks, flags, nflag);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
