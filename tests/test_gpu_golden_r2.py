@@ -88,15 +88,16 @@ def test_multi_peak_records_vs_reference(engine):
             assert list(sy.peaks[0, :k].cpu().numpy()) == ref[:k], (t, name)
 
 
-@pytest.mark.parametrize("multi", [0, 1, 2])
+@pytest.mark.parametrize("multi", [0, 1, 2, 3])
 def test_polar_bulk_vs_reference(engine, multi):
     """1 024 LLR vectors: final SCL-8 lists bit-identical (bits, metrics, CRC flags) to the reference run on the C
-    library's exp/log1p; hard-decision shortcut and (info, ok) through es_select_batch.  All three mappings: one frame
-    per wave (0), 16 paths x 4 lanes per wave (1), 32 paths x 2 lanes per wave (2)."""
+    library's exp/log1p; hard-decision shortcut and (info, ok) through es_select_batch.  All four mappings: one frame
+    per wave (0), 16 paths x 4 lanes per wave (1), 32 paths x 2 lanes per wave (2), 64 paths x 1 lane per wave (3: es_scl_wide.hip,
+    the kernel of the grouped headline and of the large launches)."""
     g = _g("polar_bulk_glibc.npz")
     llr, = _dev(engine, g["llr"])
     engine.set_option("scl_multi", 1 if multi else 0)
-    engine.set_option("scl_lanes", 2 if multi == 2 else 4)
+    engine.set_option("scl_lanes", {0: 4, 1: 4, 2: 2, 3: 1}[multi])
     try:
         res = engine.scl(llr, list_size=8, skip_if_hard_ok=False)
         short = engine.scl(llr, list_size=8, skip_if_hard_ok=True)
