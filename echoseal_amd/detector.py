@@ -103,9 +103,9 @@ class WatermarkDetector:
         """verify() for several recordings ("full batched verify()"): the result, the order of tries
         and the evolution of `session_nonce` are those of calling the reference's verify() on the clips one after the other
         (rtwm/detector.py:44-53, 105-152); what is batched is the GPU work.  Per group of equally long clips: ONE sync launch
-        sequence over (clips x 4 bands) records and ONE header decode over every peak that can hold a frame; then, clip
-        by clip, ONE demodulate + list-decode + validate batch over the (peak, counter) candidates of all four bands, walked on the
-        host band by band in the reference's order with its early return."""
+        sequence over (clips x 4 bands) records, ONE header decode over every peak that can hold a frame and ONE demodulate +
+        list-decode + validate batch over the (peak, counter) candidates of all clips and bands; the host then walks clip by clip
+        and band by band in the reference's order with its early returns."""
         fs_list = list(fs_in) if isinstance(fs_in, (list, tuple)) else [fs_in] * len(clips)
         signals = [np.asarray(self._conditioned(c, f)).reshape(-1) for c, f in zip(clips, fs_list)]
         signals = [sg if sg.dtype == np.int16 else sg.astype(np.float32, copy=False) for sg in signals]
@@ -119,11 +119,33 @@ class WatermarkDetector:
                 continue
             for i, sc in zip(idx, self._scan_prepare([signals[i] for i in idx], order)):
                 scans[i] = sc
+        # decoding is stateless (the validator's verdict depends on blob and counter only; nonce bookkeeping happens on the host,
+        # in _accept): the candidates of ALL clips of a group and all their bands go through one demodulate + list-decode +
+        # validate batch, and the clips are then walked in order with the reference's early returns
+        decoded: dict[int, tuple] = {}
+        for (_size, _is_i16), idx in groups.items():
+            live = [i for i in idx if scans[i] is not None]
+            if not live:
+                continue
+            plans = {i: [self._scan_plan(scans[i], bi) for bi in range(len(order))] for i in live}
+            flat = [p for i in live for plan, _ in plans[i] for p in plan]
+            results = self._decode_pairs(scans[live[0]]["frames"], [p[0] for p in flat], [p[2] for p in flat]) if flat else []
+            at = 0
+            for i in live:
+                n = sum(len(plan) for plan, _ in plans[i])
+                decoded[i] = (plans[i], results[at:at + n])
+                at += n
         out = []
         for i in range(len(signals)):
             ok = False
             if scans[i] is not None:
-                ok = self._scan_decide_all(scans[i])
+                plans_i, results = decoded[i]
+                at = 0
+                for bi, (plan, hdr_log) in enumerate(plans_i):
+                    if self._scan_replay(scans[i], bi, plan, hdr_log, results[at:at + len(plan)]):
+                        ok = True
+                        break
+                    at += len(plan)
             out.append(ok)
         return out
 
