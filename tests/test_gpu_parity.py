@@ -488,6 +488,35 @@ def test_decode_pipeline_equals_decode_batch(engine, mode):
         assert torch.equal(scl.cand_ok, rc.cand_ok)
 
 
+def test_grouped_pipeline_full_size_groups(engine):
+    """The arrangement bench.py's headline runs, at its size: 40 batches of 1 024 frames (frames generated on the device, a different
+    noise realisation per batch), groups of 16 on four front-end streams and two list-decoder streams -- two full groups decoded by
+    the one-lane-per-path kernel while the next group's front ends run, and an incomplete group of 8.  Every batch's rows equal
+    decode_batch's for that batch."""
+    from echoseal_amd.engine import DecodePipeline
+    pipe = DecodePipeline(engine, list_size=8, lanes=4, scl_streams=2, group=16)
+    clean, _ = engine.synthetic_frames(KEY, 0, 1024)
+    sec = WatermarkEmbedder(KEY).sec
+    pn, band = engine.schedule(sec._prng.sub_key, KEY, ctr0=0, n=1024)
+    gen = torch.Generator(device=engine.device); gen.manual_seed(77)
+    batches = []
+    for k in range(40):
+        sigma = (0.0, 0.05, 0.2, 0.5)[k % 4]
+        batches.append((clean + sigma * torch.randn(clean.shape, generator=gen, device=engine.device, dtype=torch.float32)).contiguous() if sigma else clean)
+    torch.cuda.synchronize()
+    out = [pipe.submit(f, band, pn) for f in batches]                   # all enqueued back to back
+    pipe.synchronize()
+    for f, (sy, llr, ticket, _) in list(zip(batches, out))[::3]:
+        scl = ticket.result()
+        rs, rl, rc = engine.decode_batch(f, band, pn, list_size=8)
+        torch.cuda.synchronize()
+        assert torch.equal(sy.thr, rs.thr) and torch.equal(sy.peaks, rs.peaks) and torch.equal(sy.npeaks, rs.npeaks)
+        assert torch.equal(llr, rl)
+        for name in ("hard_info", "hard_ok", "ncand", "cand_info", "cand_metric", "cand_ok"):
+            assert torch.equal(getattr(scl, name), getattr(rc, name)), name
+    assert int((out[-1][2].result().ncand > 0).sum()) > 900             # (the list decoder did run: few frames pass the hard-decision CRC)
+
+
 def _sealed_blobs(rng, n, key=KEY):
     """n 55-byte blobs: sealed ESAL payloads, a third of them corrupted, some with a wrong magic / counter."""
     from echoseal_amd.crypto import SecureChannel
