@@ -446,18 +446,21 @@ class RxEngine:
 
 
 class DecodePipeline:
-    """Streaming form of `RxEngine.decode_batch`, several batches in flight.
+    """Streaming form of `RxEngine.decode_batch`: several batches in flight.  Batches are independent; per batch the kernels'
+    inputs and results are those of decode_batch in every arrangement.  Three arrangements:
 
-    The list decoder of a 1 024-frame batch keeps ONE wave on every SIMD and is bound by FP64 issue and
-    latency: a lone wave gets every other issue slot, so half of the vector unit idles.  Batches are
-    independent, so `submit` enqueues
-      * the front end (band-pass, float32 correlation screen + exact float64 peak picking; the LLR kernel on
-        a side stream next to sync, as in decode_batch) on one HIP stream, and
-      * the list decoder on one of `scl_streams` further streams, alternating, ordered after its front end
-        by an event.  Each of those streams decodes through its own context (own scratch slab), so two list
-        decoders can be resident at once: two waves per SIMD, the occupancy a 4 096-frame batch would have.
-    At most `depth` (= scl_streams) batches are in flight.  Results are complete after `wait(result)` / `synchronize()`;
-    values are those of decode_batch (same kernels, same order per batch)."""
+      * group=G (the throughput arrangement, bench.py's headline): the front ends (band-pass, fused sync, demodulator) of G
+        consecutive batches run on `lanes` high-priority HIP streams and fill one LLR buffer; ONE list-decoder launch -- one
+        lane per path, 64/L frames per wave, the mapping with the fewest instructions per frame -- decodes the group on one
+        of `scl_streams` further streams.  A batch's list-decoder rows are a slice of its group's result
+        (`GroupTicket.result()`), complete when the group's launch is; `synchronize()` / `wait` decode an incomplete group.
+      * lanes=K: K independent whole-chain lanes, each one HIP stream with its own context that runs band-pass .. list decoder
+        of its batches (k, k+K, ...) in order; rows of a batch within a few milliseconds of its submission.
+      * neither (round 1): the front end on one stream (LLR on a side stream), the list decoder on one of `scl_streams`
+        further streams, at most `depth` batches in flight.
+
+    Results are complete after `wait(result)` / `synchronize()`.  A process should keep at most GPU_MAX_HW_QUEUES (8) HIP
+    streams alive: pass `streams=` to build a further lanes pipeline on existing ones."""
 
     def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None, lanes: int = 0,
                  side_stream: bool = True, group: int = 0, streams=None):
