@@ -9,8 +9,8 @@
 //     [element][slot], so the lanes of a wave touch one contiguous row; a lane walks a node's elements serially.
 //   * depths 8 and 9 (4 + 2 values): LDS, [element][slot]; depth 10 (the leaf LLR): a register.
 //   * slot pointers (which slot holds my data at depth d): one byte per depth packed in two 64-bit registers,
-//     partial-sum blocks of 1..16 bits in one 32-bit register (as in es_scl.hip), of 32..128 bits in LDS by
-//     slot, of 256 / 512 bits (read three times per frame) in the slab.
+//     partial-sum blocks of 1..16 bits in one 32-bit register (as in es_scl.hip), of 32 and 64 bits in LDS by
+//     slot, of 128 / 256 / 512 bits (read a few times per frame) in the slab.
 //   * a sort moves registers only: every path publishes (pointers, small partial sums, trace-back window, the
 //     softplus pair of the even sibling) to LDS, and the survivor of rank r -- lane r -- reads its parent's.
 //   * trace-back by windows of 32 information bits (as in es_scl_multi.hip): a path carries the bits of the
@@ -61,8 +61,8 @@ struct WideArgs {
 };
 
 constexpr int MWIN_W = KINFO / 32;            // trace-back windows
-// aux slab per path: windows 14 x (4 + 2) B, partial-sum blocks of 256 / 512 bits 24 x 4 B, fold scratch 16 x 4 B
-constexpr int WIDE_AUX_PER_PATH = MWIN_W * 6 + 24 * 4 + 16 * 4;
+// aux slab per path: windows 14 x (4 + 2) B, partial-sum blocks of 128 / 256 / 512 bits 28 x 4 B, fold scratch 16 x 4 B
+constexpr int WIDE_AUX_PER_PATH = MWIN_W * 6 + 28 * 4 + 16 * 4;
 
 // NB = 2: buffers that a wave may still be reading while another wave is already a sort further (several waves per frame);
 // a block that is one wave runs in order and needs one of each.
@@ -76,7 +76,7 @@ struct WideLds {
     uint64_t xpb[NB][L];                // ... partial-sum slot pointers | depth-9 pointer << 40 | window ancestor << 48,
     uint32_t xb0[NB][L];                // ... partial sums of 1..16 bits,
     uint32_t xhist[NB][L];              // ... bits of the current trace-back window
-    uint32_t betaM[7][L];               // partial-sum blocks of 32 (row 0), 64 (1, 2), 128 bits (3..6), by slot
+    uint32_t betaM[3][L];               // partial-sum blocks of 32 (row 0) and 64 bits (1, 2), by slot (wider ones, touched a few times per frame: slab)
     uint16_t sidx[NB][2 * L];
     int      flag;
     // (the hard decision's 184 bytes borrow the first wave's cells of skey[0])
@@ -340,13 +340,13 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
     double* const A = a.alpha + (long long)slot * N * L;             // element e of slot s at A[e*L + s]
     unsigned char* const aux = a.aux + (long long)slot * WIDE_AUX_PER_PATH * L;
     uint32_t* const TBW = reinterpret_cast<uint32_t*>(aux);                          // [14][L] window bits (first = MSB)
-    uint32_t* const BG = TBW + MWIN_W * L;                                           // [24][L] partial-sum blocks of 256 (rows 0..7) and 512 bits (8..23), by slot
-    uint32_t* const CB = BG + 24 * L;                                                // [16][L] fold scratch, own column only
+    uint32_t* const BG = TBW + MWIN_W * L;                                           // [28][L] partial-sum blocks of 128 (rows 0..3), 256 (4..11) and 512 bits (12..27), by slot
+    uint32_t* const CB = BG + 28 * L;                                                // [16][L] fold scratch, own column only
     uint16_t* const TBA = reinterpret_cast<uint16_t*>(CB + 16 * L);                  // [14][L] path (within the frame) at the window's start
 
     // partial-sum word `wi` (block of 32*Wd bits at words [Wd, 2Wd)) of slot s
-    auto beta_ld = [&](int wi, int s) -> uint32_t { return wi < 8 ? W.betaM[wi - 1][s] : BG[(wi - 8) * L + s]; };
-    auto beta_st = [&](int wi, int s, uint32_t v) { if (wi < 8) W.betaM[wi - 1][s] = v; else BG[(wi - 8) * L + s] = v; };
+    auto beta_ld = [&](int wi, int s) -> uint32_t { return wi < 4 ? W.betaM[wi - 1][s] : BG[(wi - 4) * L + s]; };
+    auto beta_st = [&](int wi, int s, uint32_t v) { if (wi < 4) W.betaM[wi - 1][s] = v; else BG[(wi - 4) * L + s] = v; };
 
     uint32_t* const hd_words = reinterpret_cast<uint32_t*>(&W.skey[0][0]);                  // 32 words ...
     uint8_t* const hd_bytes = reinterpret_cast<uint8_t*>(&W.skey[0][16]);                   // ... and 56 bytes of the hard decision (first wave)
@@ -645,6 +645,7 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
 {
     const size_t lds = sizeof(WideLds<L, (LF > 64 ? 2 : 1)>);
     static_assert((sizeof(WideLds<256, 2>) + 1279) / 1280 * 1280 * 3 <= 160 * 1024, "three workgroups per CU at L = 256 (LDS is handed out in 1 280-byte granules)");
+    static_assert((sizeof(WideLds<128, 2>) + 1279) / 1280 * 1280 * 6 <= 160 * 1024, "six two-wave workgroups per CU at L = 128");
     static_assert((sizeof(WideLds<64, 1>) + 1279) / 1280 * 1280 * 12 <= 160 * 1024, "twelve one-wave workgroups per CU");
     static_assert((LF & (LF - 1)) == 0, "power of two");
     constexpr unsigned attr_bit = (unsigned)LF;                        // one instantiation per list capacity
