@@ -488,6 +488,24 @@ def test_decode_pipeline_equals_decode_batch(engine, mode):
         assert torch.equal(scl.cand_ok, rc.cand_ok)
 
 
+def test_pipeline_on_given_streams(engine):
+    """DecodePipeline(streams=...) runs its lanes on existing HIP streams (a process should not keep more than eight alive):
+    same rows as decode_batch; a wrong number of streams is refused."""
+    from echoseal_amd.engine import DecodePipeline
+    st = [torch.cuda.Stream(engine.device) for _ in range(2)]
+    pipe = DecodePipeline(engine, list_size=4, lanes=2, streams=st)
+    assert pipe.lane_streams == st
+    dev = [_dev(engine, *_workload(128, noise=n, seed=40 + k, ctr0=500 * k)) for k, n in enumerate((0.0, 0.3, 0.1))]
+    out = [pipe.submit(f, b, p) for f, b, p in dev]
+    pipe.synchronize()
+    for (f, b, p), (sy, llr, scl, done) in zip(dev, out):
+        rs, rl, rc = engine.decode_batch(f, b, p, list_size=4)
+        torch.cuda.synchronize()
+        assert torch.equal(llr, rl) and torch.equal(scl.cand_info, rc.cand_info) and torch.equal(scl.cand_metric, rc.cand_metric)
+    with pytest.raises(ValueError):
+        DecodePipeline(engine, list_size=4, lanes=3, streams=st)
+
+
 def test_grouped_pipeline_full_size_groups(engine):
     """The arrangement bench.py's headline runs, at its size: 40 batches of 1 024 frames (frames generated on the device, a different
     noise realisation per batch), groups of 16 on four front-end streams and two list-decoder streams -- two full groups decoded by
