@@ -485,10 +485,14 @@ class DecodePipeline:
             for e in self.scl_engs:                   # kernel by launch size: a full group runs one lane per path, a lone batch one frame per wave
                 e.set_option("scl_multi", -1); e.set_option("scl_lanes", 0); e.set_option("scl_lane_slab", 1)
             self.front = self.side = None
-            self._ring: list = [None] * (nb + 1)      # LLR buffers of the groups in flight (+ the one being filled)
+            self._ring: list = [None] * (nb + 1)      # the most recent groups: a new group's front ends wait for the decoder of the group nb + 1 before it
             self._open = None
             self._k = self._g = 0
             self._flush_lanes = 0                     # (tests: 1 = one lane per path whatever the group's size)
+            # after an idle pipeline the first group of every decoder stream is 5/8 of a full one: a burst reaches all decoder
+            # streams sooner, and a list-decoder wave takes ~8 ms whatever its launch, so the start of the LAST launch of a
+            # burst is what its completion hangs on (a 20-batch burst as 10 + 10: 1.71 against 1.60 M frames/s as 16 + 4)
+            self._since_idle = 0
             return
         # `lanes` > 0: the other arrangement -- K independent lanes, each one HIP stream (= one hardware queue) with its
         # own context that runs the WHOLE chain of its batches (k, k+K, ...) in order; no cross-stream events at all.
@@ -590,19 +594,19 @@ class DecodePipeline:
             self._flush(g); g = None
         if g is None:
             r = self._g % len(self._ring)
-            prev = self._ring[r]
-            if prev is not None and (prev.llr.shape[0] != self.group * B):
-                prev.done.synchronize(); prev = None
-            g = _Group(self, B, bool(select), prev, self.eng.device)
-            self._ring[r] = g
+            g = _Group(self, B, bool(select), self._ring[r], self.eng.device)
+            self._ring[r] = g                         # (only its `done` event is looked at again: the throttle of the group opened R groups later)
             self._open = g
             self._g += 1
         j = self._k % self.lanes
         self._k += 1
         st, e = self.lane_streams[j], self.lane_engs[j]
         st.wait_stream(torch.cuda.current_stream(self.eng.device))
-        if g.reuse_after is not None:
-            st.wait_event(g.reuse_after)                                      # the buffer's previous group has been decoded
+        if g.throttle is not None:
+            st.wait_event(g.throttle)                                         # at most len(ring) groups in flight on the GPU
+        if j not in g.lanes_used:
+            g.lanes_used.add(j)
+            g.llr.record_stream(st)                                           # (allocated on the caller's stream, written here)
         slot = g.count
         rows = g.llr[slot * B:(slot + 1) * B]
         with torch.cuda.stream(st):
@@ -622,7 +626,7 @@ class DecodePipeline:
         g.ready.append(ready)
         g.count += 1
         ticket = GroupTicket(g, slot)
-        if g.count == self.group:
+        if g.count == g.capacity:
             self._flush(g)
         return SyncResult(y, None, thr, peaks, npeaks, flags=flags), rows, ticket, ticket
 
@@ -638,6 +642,7 @@ class DecodePipeline:
             lp <<= 1
         # one lane per path once the group gives every SIMD a wave (launches of several groups overlap); a lone batch: the library's choice
         e.set_option("scl_lanes", 1 if (g.count * g.B * lp >= 64 * 1024 or self._flush_lanes == 1) else 0)
+        g.llr.record_stream(back)
         with torch.cuda.stream(back):
             g.scl = e.scl(g.llr[:g.count * g.B], list_size=self.list_size, skip_if_hard_ok=True)
             if g.select:
@@ -657,6 +662,7 @@ class DecodePipeline:
                 self._flush(self._open)
             for st in self.lane_streams:
                 st.synchronize()
+            self._since_idle = 0
         if self.front is not None:
             self.front.synchronize(); self.side.synchronize()
         for b in self.backs:
@@ -669,8 +675,13 @@ class _Group:
     def __init__(self, pipe: DecodePipeline, B: int, select: bool, prev, device):
         self.pipe, self.B, self.select = pipe, B, select
         self.index = pipe._g
-        self.llr = prev.llr if prev is not None else torch.empty((pipe.group * B, 1024), dtype=torch.float32, device=device)
-        self.reuse_after = prev.done if prev is not None else None
+        self.capacity = pipe.group if pipe._since_idle >= len(pipe.backs) else max(1, (5 * pipe.group + 7) // 8)
+        pipe._since_idle += 1
+        # a buffer of its own (the rows handed out to the caller stay valid as long as the caller keeps them); the caching
+        # allocator is told about every stream that touches it (record_stream)
+        self.llr = torch.empty((self.capacity * B, 1024), dtype=torch.float32, device=device)
+        self.throttle = prev.done if prev is not None else None
+        self.lanes_used: set = set()
         self.ready: list = []
         self.count = 0
         self.scl = self.selected = self.done = None
