@@ -524,15 +524,16 @@ class DecodePipeline:
         self._k = 0
 
     def submit(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *,
-               start: torch.Tensor | None = None, xcorr_events=None, select: bool = False):
-        """Enqueue one batch.  start: frame starts [B] (None = 0; "peak" = the first detected peak of each record, lanes only);
+               start: torch.Tensor | None = None, xcorr_events=None, select: bool = False, inputs_ready: bool = False):
+        """Enqueue one batch.  inputs_ready (grouped arrangement): skip the wait on the caller's stream -- for inputs known to be
+        complete on the device (10 us of host time per batch).  start: frame starts [B] (None = 0; "peak" = the first detected peak of each record, lanes only);
         select (lanes only): also run the candidate selection (es_select_batch, validator None) on the lane's stream --
         the result is attached to the returned SclResult as `.selected = (payload, ok, which)`."""
         eng = self.eng
         if frames.shape[1] - 62 > eng.FAST_MAX_LAGS:
             raise ValueError("DecodePipeline serves frame-sized records (use RxEngine.decode_batch for long captures)")
         if self.group:
-            return self._submit_grouped(frames, band, pn_rows, start, xcorr_events, select)
+            return self._submit_grouped(frames, band, pn_rows, start, xcorr_events, select, inputs_ready)
         if self.lanes:
             j = self._k % self.lanes
             self._k += 1
@@ -587,7 +588,7 @@ class DecodePipeline:
         return SyncResult(y, None, thr, peaks, npeaks, flags=flags), llr, scl, done
 
     # ---- grouped arrangement
-    def _submit_grouped(self, frames, band, pn_rows, start, xcorr_events, select):
+    def _submit_grouped(self, frames, band, pn_rows, start, xcorr_events, select, inputs_ready=False):
         B = frames.shape[0]
         g = self._open
         if g is not None and (g.B != B or g.select != bool(select)):
@@ -601,7 +602,8 @@ class DecodePipeline:
         j = self._k % self.lanes
         self._k += 1
         st, e = self.lane_streams[j], self.lane_engs[j]
-        st.wait_stream(torch.cuda.current_stream(self.eng.device))
+        if not inputs_ready:                                                  # (inputs_ready: the caller vouches that frames / band / pn_rows are complete on the device)
+            st.wait_stream(torch.cuda.current_stream(self.eng.device))
         if g.throttle is not None:
             st.wait_event(g.throttle)                                         # at most len(ring) groups in flight on the GPU
         if j not in g.lanes_used:
