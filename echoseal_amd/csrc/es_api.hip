@@ -392,6 +392,11 @@ int es_set_option(es_ctx* ctx, const char* name, int value)
         ctx->scl_multi = value;
         return ES_OK;
     }
+    if (std::strcmp(name, "scl_prio") == 0) {
+        if (value < 0 || value > 3) return fail(ctx, ES_EINVAL, "es_set_option: scl_prio takes 0..3");
+        ctx->scl_prio = value;
+        return ES_OK;
+    }
     if (std::strcmp(name, "scl_lanes") == 0 || std::strcmp(name, "scl_lane_slab") == 0) {
         const bool slab_only = std::strcmp(name, "scl_lane_slab") == 0;
         if (slab_only ? (value != 1) : (value != 0 && value != 1 && value != 2 && value != 4))

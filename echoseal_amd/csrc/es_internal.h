@@ -46,6 +46,7 @@ struct es_ctx {
     unsigned wide_attr_mask = 0;      /* bit per instantiation of the lane-per-path list decoder (its list capacity 1 .. 256) */
     /* tuning (es_set_option) */
     int scl_lanes = 0;                /* lanes per path of the multi-frame list decoder: 4 (16 paths per wave), 2 (32 paths per wave), 0 = by batch size */
+    int scl_prio = 0;                 /* wave priority of the lane-per-path list decoder's launches (0..3) */
     int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
 };
 

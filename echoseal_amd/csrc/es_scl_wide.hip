@@ -58,6 +58,7 @@ struct WideArgs {
     int skip_if_hard_ok;
     int lsz;                                  // the caller's list size (<= L)
     unsigned* slot_bits; int n_slots, slot_words;   // bitmap of slab slots (one per resident block), as in es_scl_multi.hip
+    int prio;                                 // wave priority 0..3 (es_set_option "scl_prio"): a later launch of a burst may overtake an earlier one
 };
 
 constexpr int MWIN_W = KINFO / 32;            // trace-back windows
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
     static_assert(LF >= 1 && LF <= L && (L % 64) == 0 && L <= 256 && (WAVE ? L == 64 : L == LF), "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     WideLds<L, NB>& W = *reinterpret_cast<WideLds<L, NB>*>(smem_raw);
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio >= 3) __builtin_amdgcn_s_setprio(3);
     const int p = threadIdx.x;                       // slot == lane of the block
     const int lane = p & 63, wv = p >> 6;
     const int pl = p % LF;                           // path within its frame
@@ -696,6 +698,7 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
     a.cand_metric = cand_metric; a.cand_ok = cand_ok; a.ncand = ncand;
     a.skip_if_hard_ok = skip_if_hard_ok;
     a.lsz = L;
+    a.prio = ctx->scl_prio;
     int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
     switch (LP) {
         case 1:   return launch_wide<64, 1>(ctx, a, B, st);

@@ -644,6 +644,9 @@ class DecodePipeline:
             lp <<= 1
         # one lane per path once the group gives every SIMD a wave (launches of several groups overlap); a lone batch: the library's choice
         e.set_option("scl_lanes", 1 if (g.count * g.B * lp >= 64 * 1024 or self._flush_lanes == 1) else 0)
+        # the later launches of a burst run at a higher wave priority: a list-decoder wave takes ~8-10 ms whatever its launch, so a
+        # launch that starts 1-2 ms after its neighbour should not also finish 1-2 ms after it (steady state: every launch at 1)
+        e.set_option("scl_prio", min(1, g.order))                # (never above 1: the front-end kernels issue at 2 and 3)
         g.llr.record_stream(back)
         with torch.cuda.stream(back):
             g.scl = e.scl(g.llr[:g.count * g.B], list_size=self.list_size, skip_if_hard_ok=True)
@@ -678,6 +681,7 @@ class _Group:
         self.pipe, self.B, self.select = pipe, B, select
         self.index = pipe._g
         self.capacity = pipe.group if pipe._since_idle >= len(pipe.backs) else max(1, (5 * pipe.group + 7) // 8)
+        self.order = pipe._since_idle                 # position in the current burst (0 = first group after an idle pipeline)
         pipe._since_idle += 1
         # a buffer of its own (the rows handed out to the caller stay valid as long as the caller keeps them); the caching
         # allocator is told about every stream that touches it (record_stream)

@@ -216,7 +216,9 @@ int es_softplus_batch(es_ctx* ctx, const double* t_dev, int64_t n, double* out_d
  * "scl_lanes": lanes per path of the latter -- 4, 2, 1, or 0 (default: by batch size; 1 only when the context has that
  * kernel's scratch slab).  "scl_lane_slab" = 1 allocates that slab (1.6 GB; contexts created with list_size_max > 32 have
  * it from the start) without forcing anything: an allocation, so it belongs next to es_create / es_reserve, never between
- * enqueue calls that must not synchronise.  "scl_lanes" = 1 allocates it too.                                          */
+ * enqueue calls that must not synchronise.  "scl_lanes" = 1 allocates it too.  "scl_prio" (0..3, default 0): wave priority
+ * of the one-lane-per-path launches that follow -- a pipeline gives the later launch of a burst 1 so that it does not finish as
+ * much later as it started (the short front-end kernels issue at 2 and 3).                                               */
 int es_set_option(es_ctx* ctx, const char* name, int value);
 
 /* ---- the step after the list decoder ------------------------------------------------
