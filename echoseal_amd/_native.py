@@ -38,6 +38,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     "es_sync_fused_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
+    "es_front_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "es_reserve": (c_int, [c_void_p, c_int64, c_int]),
     "es_xcorr_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "es_pick_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

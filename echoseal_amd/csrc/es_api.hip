@@ -212,6 +212,18 @@ int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, 
     return es_launch_sync_fused(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, nullptr, (hipStream_t)stream);
 }
 
+int es_front_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T, const uint8_t* band_dev,
+                   const uint8_t* pn_dev, const int32_t* start_dev, double* y_dev, float* y32_dev, double* thr_dev,
+                   int32_t* peaks_dev, int32_t* npeaks_dev, uint8_t* flags_dev, float* llr_dev, void* stream)
+{
+    /* es_bpf2_batch -> es_sync_fused_batch -> es_llr_batch (variant 0) in one call: the same three launches, one trip through the binding */
+    int rc = es_bpf2_batch(ctx, frames_dev, dtype, B, T, band_dev, y_dev, y32_dev, stream);
+    if (rc != ES_OK) return rc;
+    rc = es_sync_fused_batch(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, stream);
+    if (rc != ES_OK) return rc;
+    return es_llr_batch(ctx, y_dev, B, T, start_dev, band_dev, pn_dev, 0, llr_dev, nullptr, nullptr, stream);
+}
+
 int es_reserve(es_ctx* ctx, int64_t B_max, int T_max)
 {
     if (!ctx) return ES_EINVAL;

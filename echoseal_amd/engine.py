@@ -157,6 +157,29 @@ class RxEngine:
                                                            _ptr(npeaks), _ptr(flags), self._stream()), "es_sync_fused_batch")
         return thr, peaks, npeaks, flags
 
+    def front(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *, start: torch.Tensor | None = None,
+              out: torch.Tensor | None = None):
+        """bpf2 -> sync_fused -> llr (variant 0) in one library call (es_front_batch): -> (y, thr, peaks, npeaks, flags, llr)."""
+        if frames.dim() != 2 or frames.dtype not in (torch.float32, torch.int16):
+            raise ValueError("frames must be float32 or int16 [B, T]")
+        frames = frames.contiguous()
+        B, T = frames.shape
+        dev = self.device
+        y = torch.empty((B, T), dtype=torch.float64, device=dev)
+        y32 = torch.empty((B, T), dtype=torch.float32, device=dev)
+        thr = torch.empty(B, dtype=torch.float64, device=dev)
+        peaks = torch.empty((B, nat.ES_MAX_PEAKS), dtype=torch.int32, device=dev)
+        npeaks = torch.empty(B, dtype=torch.int32, device=dev)
+        flags = torch.empty(B, dtype=torch.uint8, device=dev)
+        if out is None:
+            out = torch.empty((B, 1024), dtype=torch.float32, device=dev)
+        elif out.shape != (B, 1024) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 [B, 1024] tensor")
+        nat.check(self._ctx, self._lib.es_front_batch(self._ctx, _ptr(frames), nat.ES_DTYPE_I16 if frames.dtype == torch.int16 else nat.ES_DTYPE_F32,
+                                                      B, T, _ptr(band), _ptr(pn_rows), _ptr(start), _ptr(y), _ptr(y32), _ptr(thr), _ptr(peaks),
+                                                      _ptr(npeaks), _ptr(flags), _ptr(out), self._stream()), "es_front_batch")
+        return y, thr, peaks, npeaks, flags, out
+
     def reserve(self, B_max: int, T_max: int) -> None:
         """Size the context's workspaces once (es_reserve): afterwards the sync entry points only enqueue."""
         nat.check(self._ctx, self._lib.es_reserve(self._ctx, int(B_max), int(T_max)), "es_reserve")
@@ -612,15 +635,18 @@ class DecodePipeline:
         slot = g.count
         rows = g.llr[slot * B:(slot + 1) * B]
         with torch.cuda.stream(st):
-            y, y32 = e.bpf2(frames, band)
-            if xcorr_events is not None:
-                xcorr_events[0].record()
-            thr, peaks, npeaks, flags = e.sync_fused(y, y32, band)
-            if xcorr_events is not None:
-                xcorr_events[1].record()
-            if isinstance(start, str):
-                start = peaks[:, 0].clamp(min=0).contiguous()
-            e.llr(y, band, pn_rows, start=start, variant=0, out=rows)
+            if xcorr_events is None and not isinstance(start, str):              # the three launches through one library call
+                y, thr, peaks, npeaks, flags, _ = e.front(frames, band, pn_rows, start=start, out=rows)
+            else:
+                y, y32 = e.bpf2(frames, band)
+                if xcorr_events is not None:
+                    xcorr_events[0].record()
+                thr, peaks, npeaks, flags = e.sync_fused(y, y32, band)
+                if xcorr_events is not None:
+                    xcorr_events[1].record()
+                if isinstance(start, str):
+                    start = peaks[:, 0].clamp(min=0).contiguous()
+                e.llr(y, band, pn_rows, start=start, variant=0, out=rows)
             ready = torch.cuda.Event()
             ready.record()
         for t in (frames, band, pn_rows):

@@ -117,6 +117,14 @@ int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, 
                         const uint8_t* band_dev, double* thr_dev, int32_t* peaks_dev, int32_t* npeaks_dev,
                         uint8_t* flags_dev, void* stream);
 
+/* The receive front end of one batch in one call -- es_bpf2_batch, es_sync_fused_batch and es_llr_batch (variant 0, start_dev as
+ * there: NULL = 0) enqueued on `stream` in that order: what a streaming pipeline submits per batch (one trip through the
+ * binding instead of three; same kernels, same results).  T - 62 <= 4096.
+ *   replaces rtwm/detector.py:59-99 + 296-416 for a batch of records                                                     */
+int es_front_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T, const uint8_t* band_dev,
+                   const uint8_t* pn_dev, const int32_t* start_dev, double* y_dev, float* y32_dev, double* thr_dev,
+                   int32_t* peaks_dev, int32_t* npeaks_dev, uint8_t* flags_dev, float* llr_dev, void* stream);
+
 /* Size the context's float64 correlation workspace (used by es_sync_batch without corr_dev, and by the redo pass of
  * es_pick_exact_batch) for batches of up to B_max records of T_max samples.  Allocation synchronises
  * the device: call this once, outside any stream capture; afterwards those entry points only enqueue.  Without it they

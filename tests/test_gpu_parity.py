@@ -488,6 +488,23 @@ def test_decode_pipeline_equals_decode_batch(engine, mode):
         assert torch.equal(scl.cand_ok, rc.cand_ok)
 
 
+def test_front_batch_equals_separate_calls(engine):
+    """es_front_batch (band-pass -> fused sync -> LLR in one library call) == the three calls: float32 and int16 records, given starts."""
+    frames, band, pn = _workload(200, noise=0.2, seed=9)
+    f, b, p = _dev(engine, frames, band, pn)
+    st = torch.arange(200, device=engine.device, dtype=torch.int32) % 3
+    for x in (f, (f * 20000).to(torch.int16)):
+        for start in (None, st):
+            y, thr, peaks, npeaks, flags, llr = engine.front(x, b, p, start=start)
+            y2, y32 = engine.bpf2(x, b)
+            thr2, peaks2, npeaks2, flags2 = engine.sync_fused(y2, y32, b)
+            llr2 = engine.llr(y2, b, p, start=start, variant=0)
+            for u, v in ((y, y2), (thr, thr2), (peaks, peaks2), (npeaks, npeaks2), (flags, flags2), (llr, llr2)):
+                assert torch.equal(u, v)
+    with pytest.raises(ValueError):
+        engine.front(f.double(), b, p)
+
+
 def test_pipeline_on_given_streams(engine):
     """DecodePipeline(streams=...) runs its lanes on existing HIP streams (a process should not keep more than eight alive):
     same rows as decode_batch; a wrong number of streams is refused."""
