@@ -271,6 +271,7 @@ def run_rank(a) -> None:
     t0 = time.perf_counter()
     for k in range(a.steps):
         res, peaks, npeaks = step(k)
+    host_enqueue_s = time.perf_counter() - t0   # (reported: in a short run the start of the last launch hangs on it)
     pipe.synchronize()                          # (grouped pipeline: decodes the last, possibly incomplete, group)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
@@ -506,6 +507,7 @@ def run_rank(a) -> None:
                                      f"{a.scl_streams} batches in flight (DecodePipeline: front-end stream + {a.scl_streams} list-decoder streams)",
                        "untimed_preparation": "every stream / context / kernel of the pipeline runs before the clock starts (first launches allocate scratch and upload code), "
                                               "then the --warmup steps; the garbage collector is off inside the timed region",
+                       "host_enqueue_ms_of_the_timed_steps": 1e3 * host_enqueue_s, "timed_region_ms": 1e3 * dt,
                        "single_batch_latency_ms": single_ms,
                        "sync_offsets_ok": ok_sync, "frames_through_list_decoder": listed},
             "legs": out_legs,
