@@ -17,7 +17,45 @@ struct DeviceGuard {
 };
 
 int fail(es_ctx* ctx, int code, const char* msg) { ctx->err = msg; return code; }
+
+bool capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 }  // namespace
+
+int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_t st)
+{
+    if (capturing(st)) return ES_OK;                            // a captured graph orders its own nodes
+    es_ctx::slab_use& u = ctx->slab[domain];
+    const bool same = shareable && u.shareable && u.shape == shape;
+    if (!same) {
+        for (auto& e : u.users)
+            if (e.first != st) ES_HIP_CHECK(ctx, hipStreamWaitEvent(st, e.second, 0));
+        // the outstanding launches are now ordered before this one: only this stream's entry needs to stay
+        for (size_t k = 0; k < u.users.size();) {
+            if (u.users[k].first != st) { (void)hipEventDestroy(u.users[k].second); u.users.erase(u.users.begin() + (long)k); }
+            else ++k;
+        }
+    }
+    u.shape = shape; u.shareable = shareable;
+    return ES_OK;
+}
+
+int es_slab_leave(es_ctx* ctx, int domain, hipStream_t st)
+{
+    if (capturing(st)) return ES_OK;
+    es_ctx::slab_use& u = ctx->slab[domain];
+    hipEvent_t ev = nullptr;
+    for (auto& e : u.users) if (e.first == st) ev = e.second;
+    if (!ev) {
+        ES_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        u.users.emplace_back(st, ev);
+    }
+    ES_HIP_CHECK(ctx, hipEventRecord(ev, st));
+    return ES_OK;
+}
 
 extern "C" {
 
@@ -30,7 +68,7 @@ es_ctx* es_create(int device, int list_size_max)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device visible"; return nullptr; }
     if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return nullptr; }
-    if (list_size_max < 1 || list_size_max > ES_MAX_LIST) { g_create_err = "list_size_max must be in [1, 256]"; return nullptr; }
+    if (list_size_max < 0 || list_size_max > ES_MAX_LIST) { g_create_err = "list_size_max must be in [0, 256] (0: a front-end context without list-decoder scratch)"; return nullptr; }
     es_ctx* ctx = new (std::nothrow) es_ctx();
     if (!ctx) { g_create_err = "out of host memory"; return nullptr; }
     ctx->device = device;
@@ -39,8 +77,7 @@ es_ctx* es_create(int device, int list_size_max)
     hipDeviceProp_t prop;
     if (!g.ok || hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; delete ctx; return nullptr; }
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&ctx->d_nflag, sizeof(int)) != hipSuccess ||
-        hipMalloc(&ctx->d_tables, sizeof(es_band_tables)) != hipSuccess ||
+    if (hipMalloc(&ctx->d_tables, sizeof(es_band_tables)) != hipSuccess ||
         hipMalloc(&ctx->d_data_pos, sizeof(uint16_t) * ES_POLAR_N) != hipSuccess ||
         hipMalloc(&ctx->d_exp_tab, sizeof(kExpTab)) != hipSuccess ||
         hipMemcpy(ctx->d_exp_tab, kExpTab, sizeof(kExpTab), hipMemcpyHostToDevice) != hipSuccess) {
@@ -48,6 +85,7 @@ es_ctx* es_create(int device, int list_size_max)
         es_destroy(ctx);
         return nullptr;
     }
+    if (list_size_max == 0) return ctx;                /* front-end context (band-pass, sync, demodulator, header, TX ...): no list-decoder slabs */
     /* every launch-time buffer the SCL kernel needs is allocated here, so es_scl_batch only
        enqueues work (hipGraph-capturable) */
     ctx->scl_scratch_bytes = es_scl_scratch_bytes(ctx);
@@ -93,7 +131,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_wide_slot_bits) (void)hipFree(ctx->d_wide_slot_bits);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
     if (ctx->d_hdr_pn) (void)hipFree(ctx->d_hdr_pn);
-    if (ctx->d_nflag) (void)hipFree(ctx->d_nflag);
+    for (auto& u : ctx->slab) for (auto& e : u.users) (void)hipEventDestroy(e.second);
     delete ctx;
 }
 
@@ -216,7 +254,15 @@ int es_front_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, in
                    const uint8_t* pn_dev, const int32_t* start_dev, double* y_dev, float* y32_dev, double* thr_dev,
                    int32_t* peaks_dev, int32_t* npeaks_dev, uint8_t* flags_dev, float* llr_dev, void* stream)
 {
-    /* es_bpf2_batch -> es_sync_fused_batch -> es_llr_batch (variant 0) in one call: the same three launches, one trip through the binding */
+    /* es_bpf2_batch -> es_sync_fused_batch -> es_llr_batch (variant 0) in one call: the same three launches, one trip through the binding.
+       Every argument is checked before the first launch, so a bad call enqueues nothing. */
+    ES_REQUIRE_READY(ctx);
+    if (B < 0 || T < 0) return fail(ctx, ES_EINVAL, "es_front_batch: negative size");
+    if (dtype != ES_DTYPE_F32 && dtype != ES_DTYPE_I16) return fail(ctx, ES_EINVAL, "es_front_batch: dtype must be f32 or i16");
+    if (B == 0) return ES_OK;
+    if (T < ES_PRE_L) return fail(ctx, ES_EINVAL, "es_front_batch: record shorter than the 63-chip template");
+    if (!frames_dev || !band_dev || !pn_dev || !y_dev || !y32_dev || !thr_dev || !peaks_dev || !npeaks_dev || !flags_dev || !llr_dev)
+        return fail(ctx, ES_EINVAL, "es_front_batch: null pointer");
     int rc = es_bpf2_batch(ctx, frames_dev, dtype, B, T, band_dev, y_dev, y32_dev, stream);
     if (rc != ES_OK) return rc;
     rc = es_sync_fused_batch(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, stream);
@@ -320,6 +366,7 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     ES_REQUIRE_READY(ctx);
     if (B < 0) return fail(ctx, ES_EINVAL, "es_scl_batch: negative batch");
     if (dtype != ES_DTYPE_F32 && dtype != ES_DTYPE_F64) return fail(ctx, ES_EINVAL, "es_scl_batch: dtype must be f32 or f64");
+    if (ctx->list_size_max == 0) return fail(ctx, ES_EINVAL, "es_scl_batch: this is a front-end context (es_create with list_size_max = 0): it has no list-decoder scratch");
     if (list_size < 1 || list_size > ctx->list_size_max)
         return fail(ctx, ES_EINVAL, "es_scl_batch: list_size must be in [1, list_size_max]");
     if (B == 0) return ES_OK;

@@ -16,7 +16,8 @@
 // slab, depths 8..10 in registers.  Blocks are NOT persistent: a wave decodes one group of FR frames and leaves, so that
 // kernels of other streams (the front end of the next batch) get wave slots as this launch proceeds; the block's part of
 // the slab is a slot claimed from a bitmap at block start and released at its end, which also lets concurrent launches
-// of one context share the slab.  Reference lines as in es_scl.hip (rtwm/fastpolar.py:254-359).
+// of one context share the slab -- launches of the SAME slot geometry (same lanes per path): a bit maps to a different slab region per
+// geometry, so es_slab_enter (es_api.hip) orders a launch of another geometry, on another stream, behind the outstanding ones.  Reference lines as in es_scl.hip (rtwm/fastpolar.py:254-359).
 //
 // Build with -ffp-contract=off: every rounding step in es_math.h is explicit.
 #include "es_scl_common.h"
@@ -576,9 +577,10 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     SclArgs a = a0;
     a.scratch = ctx->d_scl_scratch;
     a.slot_bits = ctx->d_slot_bits; a.n_slots = n_slots; a.slot_words = (n_slots + 31) / 32;
+    { const int rc = es_slab_enter(ctx, 0, 0x200 | PP, true, st); if (rc) return rc; }      // slot stride depends on PP only
     hipLaunchKernelGGL((es_scl_multi_kernel<L, PP>), dim3((unsigned)blocks), dim3(64 * MWPB), 0, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
-    return ES_OK;
+    return es_slab_leave(ctx, 0, st);
 }
 
 }  // namespace

@@ -665,9 +665,10 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
     a.slot_bits = ctx->d_wide_slot_bits;
     a.n_slots = ctx->wide_slots * (Lm / L);
     a.slot_words = (a.n_slots + 31) / 32;
+    { const int rc = es_slab_enter(ctx, 1, 0x300 | L, true, st); if (rc) return rc; }       // slot stride depends on the block's lanes only
     hipLaunchKernelGGL((es_scl_wide_kernel<L, LF>), dim3((unsigned)blocks), dim3(L), lds, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
-    return ES_OK;
+    return es_slab_leave(ctx, 1, st);
 }
 
 }  // namespace

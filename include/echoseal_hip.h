@@ -39,7 +39,7 @@ extern "C" {
 #define ES_NBANDS         4
 #define ES_MAX_TAPS     160   /* reference taps are 93..131 long (rtwm/detector.py:260-294) */
 #define ES_MAX_PEAKS     32   /* detector consumes at most 25 peaks per scan (rtwm/detector.py:108) */
-#define ES_MAX_LIST     256   /* 1..32: one wavefront per frame; 64..256: one workgroup per frame */
+#define ES_MAX_LIST     256   /* any list size 1..256; the mapping of paths to lanes is chosen per launch (es_set_option) */
 #define ES_PN_BYTES     152   /* ceil(1215 / 8): packed PN row of one frame counter */
 
 #define ES_DTYPE_F32      0
@@ -48,7 +48,9 @@ extern "C" {
 
 typedef struct es_ctx es_ctx;
 
-/* Context: binds a device, owns table / scratch memory. */
+/* Context: binds a device, owns table / scratch memory.  list_size_max 1..256: the largest list es_scl_batch will be asked for (sizes
+ * the list decoder's scratch slabs, 0.4 GB; above 32 also the 1.6 GB lane-per-path slab).  list_size_max = 0: a FRONT-END context --
+ * every entry point except es_scl_batch, no list-decoder scratch at all (what a pipeline's band-pass / sync / demodulator streams use). */
 es_ctx*     es_create(int device, int list_size_max);
 void        es_destroy(es_ctx* ctx);
 const char* es_last_error(const es_ctx* ctx);          /* ctx may be NULL (creation errors) */
@@ -129,7 +131,12 @@ int es_front_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, in
  * es_pick_exact_batch) for batches of up to B_max records of T_max samples.  Allocation synchronises
  * the device: call this once, outside any stream capture; afterwards those entry points only enqueue.  Without it they
  * grow the workspace themselves the first time a larger batch arrives (same effect as calling es_reserve there).
- * One stream at a time per context: the workspace and the list decoder's scratch slab are shared by every call on it.   */
+ * es_reserve does not cover the list decoder: its slabs are allocated by es_create, and the 1.6 GB lane-per-path slab of contexts with
+ * list_size_max <= 32 by es_set_option "scl_lane_slab" / "scl_lanes" = 1 -- set those before the first enqueue-only call as well.
+ * Streams: the float64 workspace is shared by every call on the context (one stream at a time for the entry points that use it).  The list
+ * decoder's slabs are guarded: es_scl_batch launches on one stream are ordered by the stream, launches of the same slot geometry on several
+ * streams share the slab through its slot bitmap, and a launch of another geometry on another stream is made to wait (hipStreamWaitEvent)
+ * for the outstanding ones.                                                                                                          */
 int es_reserve(es_ctx* ctx, int64_t B_max, int T_max);
 
 /* Convenience: the three float64 calls above back to back (workspace owned by the context). */

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Round-3 golden vectors: BASELINE config 5's list sweep (L = 1 / 4 / 16; L = 8 is polar_bulk_*.npz) pinned to the
+REFERENCE, captured by running it (build container only; /root/reference is read-only and never travels).  Only inputs
+and outputs are stored under tests/golden/ -- no reference source.
+
+    python -m oracle.refshim.gen_golden_r3 [all|inputs|sweep_default|sweep_glibc]
+
+    polar_sweep_{default,glibc}.npz   for each L in (1, 4, 16): 256 LLR vectors through the reference's
+        PolarCode.decode(list_size=L) (rtwm/fastpolar.py:254-359): (info, ok), whether the list loop ran, and the final
+        list in the order of the reference's last sort (bits, metrics, CRC flags).  Mix per L (disjoint between the Ls):
+          64  detector-produced: the reference's _llr (PN variant 1) on BASELINE-config-3 windows
+              (c3_windows.npz rows, computed by the reference in round 2: rtwm/detector.py:296-416)
+          64  detector-produced through the config-5 SURROGATE channel (echoseal_amd.workloads.lossy_channel, NOT MP3):
+              reference embedder frame -> lossy_channel -> reference band-pass (scipy lfilter) -> reference _llr
+              (variant 0, start 0)
+          64  AWGN on random codewords, sigma 0.3 .. 1.1, clipped to +-12
+          64  tie-heavy (few distinct magnitudes, zeros, +-12)
+        Both NumPy run-time modes (see gen_golden.py: `default` = AVX-512 exp/log1p dispatch, `glibc` = C library).
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import subprocess
+import sys
+
+AVX512_OFF = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GOLD = os.path.join(ROOT, "tests", "golden")
+KEY = b"\xAA" * 32
+LISTS = (1, 4, 16)
+PER_L = 256
+INPUTS = os.path.join(GOLD, "polar_sweep_inputs.npz")
+
+
+def gen_inputs():
+    """The 3 x 256 LLR vectors (float32).  The detector-produced rows come from the reference's own _llr."""
+    import numpy as np
+    from oracle.refshim.shim import load_reference
+    load_reference()
+    from rtwm.detector import WatermarkDetector
+    from rtwm.utils import choose_band, butter_bandpass
+    from scipy.signal import lfilter
+    from echoseal_amd.polar_fast import encode
+    from echoseal_amd.workloads import lossy_channel
+    from oracle.refshim.gen_golden_r2 import ref_frames
+    c3 = np.load(os.path.join(GOLD, "c3_windows.npz"))
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        rx = WatermarkDetector(KEY, list_size=8)
+    ctrs = list(range(1000, 1000 + 64 * len(LISTS)))                  # frames no other fixture uses
+    frames, _ = ref_frames(np, ctrs)
+    lossy = lossy_channel(frames)
+    out, kinds = {}, {}
+    for li, L in enumerate(LISTS):
+        rng = np.random.default_rng(30260 + L)
+        rows, kind = [], []
+        for i in range(64):                                           # reference _llr, PN variant 1, on C3 windows
+            rows.append(c3["llr1"][64 * li + i].astype(np.float32)); kind.append(0)
+        for i in range(64):                                           # reference _llr on the lossy-channel frames
+            c = ctrs[64 * li + i]
+            b, a = butter_bandpass(*choose_band(KEY, c), 48000, order=4)
+            y = lfilter(b, a, lossy[64 * li + i].astype(np.float32, copy=False))
+            with contextlib.redirect_stdout(sink):
+                rows.append(np.asarray(rx._llr(y, c, 0), np.float32))
+            kind.append(1)
+        for i in range(64):                                           # AWGN on random codewords
+            sigma = (0.3, 0.45, 0.6, 0.75, 0.9, 1.0, 1.1, 0.5)[i % 8]
+            code = encode(rng.integers(0, 256, 55, dtype=np.uint8).tobytes())
+            r = 2.0 * code.astype(np.float64) - 1.0 + rng.normal(0, sigma, 1024)
+            rows.append(np.clip(2.0 * r / sigma ** 2, -12, 12).astype(np.float32)); kind.append(2)
+        for i in range(64):                                           # tie-heavy
+            levels = ((0.0, 12.0), (1.0,), (0.5, 1.0, 1.5), (0.0, 2.0, 4.0), (12.0,), (0.0, 0.25), (0.0,), (3.0, 12.0))[i % 8]
+            mag = rng.choice(np.array(levels), 1024)
+            sign = rng.integers(0, 2, 1024) * 2.0 - 1.0
+            v = (mag * sign).astype(np.float32)
+            if i % 16 >= 8 and levels[-1]:                            # partly a real codeword at one magnitude
+                code = encode(rng.integers(0, 256, 55, dtype=np.uint8).tobytes())
+                flips = rng.random(1024) < 0.04
+                v = ((2.0 * (code ^ flips) - 1.0) * levels[-1]).astype(np.float32)
+            rows.append(v); kind.append(3)
+        out[f"L{L}/llr"] = np.stack(rows)
+        kinds[f"L{L}/kind"] = np.array(kind, np.uint8)
+        print(f"  inputs L={L}: {len(rows)} rows", flush=True)
+    np.savez_compressed(INPUTS, **out, **kinds)
+
+
+def _worker(args):
+    L, lo, hi = args
+    import builtins
+    import numpy as np
+    from oracle.refshim.shim import load_reference
+    load_reference()
+    import rtwm.fastpolar as fp
+    llrs = np.load(INPUTS)[f"L{L}/llr"]
+    captured = {}
+
+    def spy_sorted(seq, key=None):
+        out = builtins.sorted(seq, key=key)
+        if seq and hasattr(seq[0], "metric"):
+            captured["metric"] = np.array([p.metric for p in out], dtype=np.float64)
+            captured["u"] = np.stack([p.u.copy() for p in out])
+        return out
+    fp.sorted = spy_sorted                                            # module-global lookup precedes builtins
+    pc = fp.PolarCode(1024, 448, list_size=L, crc_size=8)
+    res = []
+    for i in range(lo, hi):
+        captured.clear()
+        bits, ok = pc.decode(llrs[i])
+        if captured:
+            data = captured["u"][:, pc._data_pos]
+            ci = np.packbits(data[:, :440], axis=1)
+            cc = np.array([pc._crc_ok(d[:440], d[440:448]) for d in data], dtype=np.uint8)
+            res.append((np.packbits(bits), bool(ok), True, ci, captured["metric"].copy(), cc))
+        else:
+            res.append((np.packbits(bits), bool(ok), False, None, None, None))
+    return L, lo, res
+
+
+def gen_sweep(mode, workers=6):
+    import multiprocessing as mp
+    import numpy as np
+    inp = np.load(INPUTS)
+    out = {"meta_mode": np.array(mode), "meta_numpy": np.array(np.__version__), "lists": np.array(LISTS)}
+    store = {}
+    jobs = []
+    for L in LISTS:
+        n = inp[f"L{L}/llr"].shape[0]
+        store[L] = dict(info=np.zeros((n, 55), np.uint8), ok=np.zeros(n, bool), took=np.zeros(n, bool),
+                        ci=np.zeros((n, L, 55), np.uint8), cm=np.zeros((n, L)), cc=np.zeros((n, L), np.uint8), nc=np.zeros(n, np.int32))
+        step = 32 if L == 1 else 16 if L == 4 else 8
+        jobs += [(L, lo, min(n, lo + step)) for lo in range(0, n, step)]
+    jobs.sort(key=lambda j: -j[0])                                   # the long ones first
+    with mp.get_context("spawn").Pool(workers) as pool:
+        for L, lo, res in pool.imap_unordered(_worker, jobs):
+            s = store[L]
+            for j, r in enumerate(res):
+                i = lo + j
+                s["info"][i], s["ok"][i], s["took"][i] = r[0], r[1], r[2]
+                if r[2]:
+                    k = r[4].shape[0]
+                    s["nc"][i] = k
+                    s["ci"][i, :k], s["cm"][i, :k], s["cc"][i, :k] = r[3], r[4], r[5]
+            print(f"  sweep[{mode}] L={L} {lo}..{lo + len(res)}: ok {int(s['ok'][lo:lo + len(res)].sum())} list {int(s['took'][lo:lo + len(res)].sum())}", flush=True)
+    for L in LISTS:
+        s = store[L]
+        out.update({f"L{L}/info": s["info"], f"L{L}/ok": s["ok"], f"L{L}/took_list": s["took"], f"L{L}/cand_info": s["ci"],
+                    f"L{L}/cand_metric": s["cm"], f"L{L}/cand_crc": s["cc"], f"L{L}/ncand": s["nc"]})
+        if mode == "glibc":
+            out[f"L{L}/llr"] = inp[f"L{L}/llr"]; out[f"L{L}/kind"] = inp[f"L{L}/kind"]
+    np.savez_compressed(os.path.join(GOLD, f"polar_sweep_{mode}.npz"), **out)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    if what == "all":
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "inputs"], cwd=ROOT, env=env)
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "sweep_default"], cwd=ROOT, env=env)
+        env["NPY_DISABLE_CPU_FEATURES"] = AVX512_OFF
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "sweep_glibc"], cwd=ROOT, env=env)
+        os.remove(INPUTS)                                             # (the inputs live in polar_sweep_glibc.npz)
+    elif what == "inputs":
+        gen_inputs()
+    elif what in ("sweep_default", "sweep_glibc"):
+        gen_sweep(what.split("_")[1], workers=int(os.environ.get("GOLD_WORKERS", "6")))
+    else:
+        raise SystemExit(f"unknown target {what}")
+
+
+if __name__ == "__main__":
+    main()

@@ -4,13 +4,14 @@ itself, captured by oracle/refshim/gen_golden_r2.py (which imports and runs /roo
     c3_windows.npz       256 BASELINE-config-3 windows through the reference's own _scan_band_multi_frame, _decode_header, _llr
     sync_multi.npz       records with 2-5 peaks (3-frame clips, frame-sized records with a second peak), same capture
     polar_bulk_*.npz     1 024 LLR vectors through PolarCode.decode(list_size=8), final lists, both NumPy run-time modes
+    polar_sweep_*.npz    (round 3) 3 x 256 LLR vectors through PolarCode.decode at list sizes 1, 4 and 16 (BASELINE config 5's sweep)
     polar_validator.npz  PolarCode.decode with validators: every payload the validator was shown, in order
     verify3s.npz         verify() on a 3 s noisy clip: tries, header decodes (host flow: tests/test_detector.py on the GPU)
 
 Bars (BASELINE.json north_star): sync offsets / decoded bits exact, LLR within 1e-5.  The LLR shift search is the one
 place where the reference is not bit-reproducible across machines (float32 BLAS rounding): a frame whose
 best / runner-up scores differ by less than 1e-5 relative is classified TIE-AMBIGUOUS when the chosen shift differs,
-and the report (tests/golden/h1_margin_report.json, written by this test) counts them instead of failing.
+and the report (tests/golden/h1_margin_report.json, asserted by this test; ES_WRITE_H1_REPORT=1 rewrites it) counts them. Observed: none.
 """
 import json
 import os
@@ -104,9 +105,18 @@ def test_c3_windows_header_and_llr_match_reference(oracle, tables):
                                                     "below_1e-5": int((rows < 1e-5).sum()), "below_1e-4": int((rows < 1e-4).sum())},
               "worst_abs_llr_error_vs_reference": worst,
               "note": "256 config-3 windows x PN variants 0/1, oracle vs reference _llr at the reference's first peak"}
-    with open(os.path.join(HERE, "golden", "h1_margin_report.json"), "w") as fh:
-        json.dump(report, fh, indent=1)
-    assert exact >= 0.98 * rows.size
+    # the committed report is an ASSERTED record of this run, not an output of it (ES_WRITE_H1_REPORT=1 regenerates it)
+    path = os.path.join(HERE, "golden", "h1_margin_report.json")
+    if os.environ.get("ES_WRITE_H1_REPORT") == "1":
+        with open(path, "w") as fh:
+            json.dump(report, fh, indent=1)
+    with open(path) as fh:
+        committed = json.load(fh)
+    assert committed["frames_x_variants"] == report["frames_x_variants"]
+    assert committed["shift_equal_to_reference"] == exact and committed["tie_ambiguous_shift_differs"] == amb
+    assert committed["relative_margin_best_vs_runner_up"]["below_1e-5"] == report["relative_margin_best_vs_runner_up"]["below_1e-5"]
+    assert abs(committed["relative_margin_best_vs_runner_up"]["min"] - report["relative_margin_best_vs_runner_up"]["min"]) <= 1e-9
+    assert amb == 0 and exact == rows.size          # observed: every chosen shift equals the reference's; the margin rule excuses nothing here
 
 
 def test_multi_peak_records_match_reference(oracle, tables):
@@ -161,6 +171,42 @@ def test_polar_bulk_matches_reference(oracle, mode):
                 assert not np.array_equal(g["cand_info"][i], _g("polar_bulk_glibc.npz")["cand_info"][i])
     assert listed >= 900
     assert metric_flips <= 2, metric_flips
+
+
+@pytest.mark.parametrize("mode", ["glibc", "default"])
+@pytest.mark.parametrize("L", [1, 4, 16])
+def test_polar_sweep_matches_reference(oracle, mode, L):
+    """BASELINE config 5 sweeps the list size over 1 / 4 / 8 / 16: 256 vectors per size (detector-produced on C3 windows and through
+    the config-5 surrogate channel, AWGN, tie-heavy) through the reference's PolarCode.decode (oracle/refshim/gen_golden_r3.py)."""
+    g = _g(f"polar_sweep_{mode}.npz")
+    gl = _g("polar_sweep_glibc.npz")
+    llrs, kinds = gl[f"L{L}/llr"], gl[f"L{L}/kind"]          # 0 C3 detector, 1 lossy-channel detector, 2 AWGN, 3 tie-heavy
+    n = llrs.shape[0]
+    assert n == 256
+    listed = flips = 0
+    for i in range(n):
+        info, ok, took = oracle.polar_decode(llrs[i], L)
+        assert took == bool(g[f"L{L}/took_list"][i]), i
+        if not took:
+            assert ok == bool(g[f"L{L}/ok"][i]) and np.array_equal(np.packbits(info), g[f"L{L}/info"][i]), i
+            continue
+        listed += 1
+        nn, ci, cm, cc = oracle.scl_list(llrs[i], L)
+        assert nn == int(g[f"L{L}/ncand"][i]) == L, i
+        same_bits = np.array_equal(np.packbits(ci, axis=1), g[f"L{L}/cand_info"][i])
+        if mode == "glibc":
+            assert np.array_equal(cm.view(np.uint64), g[f"L{L}/cand_metric"][i].view(np.uint64)), i
+            assert same_bits and np.array_equal(cc, g[f"L{L}/cand_crc"][i]), i
+            assert ok == bool(g[f"L{L}/ok"][i]) and np.array_equal(np.packbits(info), g[f"L{L}/info"][i]), i
+        elif same_bits:
+            assert np.allclose(cm, g[f"L{L}/cand_metric"][i], rtol=1e-12, atol=0), i
+            assert ok == bool(g[f"L{L}/ok"][i]) and np.array_equal(np.packbits(info), g[f"L{L}/info"][i]), i
+        else:                                   # the reference's two NumPy modes break an exact tie differently: tie-heavy rows only
+            flips += 1
+            assert kinds[i] == 3, (i, int(kinds[i]))
+            assert not np.array_equal(g[f"L{L}/cand_info"][i], gl[f"L{L}/cand_info"][i])
+    assert listed >= 200
+    assert flips <= 2, flips
 
 
 def _scl_result_from_oracle(oracle, llr, L):

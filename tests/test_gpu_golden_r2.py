@@ -71,7 +71,7 @@ def test_c3_windows_sync_header_llr_vs_reference(engine):
                 amb += 1
                 continue
             worst = max(worst, float(np.max(np.abs(llr[i] - g[key][i]))))
-    assert worst <= 1e-5 and amb <= 4, (worst, amb)
+    assert worst <= 1e-5 and amb == 0, (worst, amb)          # observed: no shift differs (tests/golden/h1_margin_report.json)
 
 
 def test_multi_peak_records_vs_reference(engine):
@@ -111,6 +111,30 @@ def test_polar_bulk_vs_reference(engine, multi):
     payload, ok, which = engine.select(short)
     assert np.array_equal(payload.cpu().numpy(), g["info"])
     assert np.array_equal(ok.cpu().numpy() == 1, g["ok"])
+
+
+@pytest.mark.parametrize("L", [1, 4, 16])
+def test_polar_sweep_vs_reference(engine, L):
+    """BASELINE config 5's list sizes (1 / 4 / 16; 8 is the bulk test above): 256 vectors per size, final lists bit-identical (bits, metrics,
+    CRC flags) to the reference run on the C library's exp/log1p, on every mapping that serves the size; (info, ok) through es_select_batch."""
+    g = _g("polar_sweep_glibc.npz")
+    llr, = _dev(engine, g[f"L{L}/llr"])
+    took = g[f"L{L}/took_list"]
+    for multi in (0, 1, 2, 3):
+        engine.set_option("scl_multi", 1 if multi else 0)
+        engine.set_option("scl_lanes", {0: 4, 1: 4, 2: 2, 3: 1}[multi])
+        try:
+            res = engine.scl(llr, list_size=L, skip_if_hard_ok=False)
+            short = engine.scl(llr, list_size=L, skip_if_hard_ok=True)
+        finally:
+            engine.set_option("scl_multi", -1); engine.set_option("scl_lanes", 0)
+        assert np.array_equal(short.ncand.cpu().numpy() > 0, took), multi
+        assert np.array_equal(res.cand_info.cpu().numpy()[took], g[f"L{L}/cand_info"][took]), multi
+        assert np.array_equal(res.cand_metric.cpu().numpy()[took].view(np.uint64), g[f"L{L}/cand_metric"][took].view(np.uint64)), multi
+        assert np.array_equal(res.cand_ok.cpu().numpy()[took], g[f"L{L}/cand_crc"][took]), multi
+        payload, ok, which = engine.select(short)
+        assert np.array_equal(payload.cpu().numpy(), g[f"L{L}/info"]), multi
+        assert np.array_equal(ok.cpu().numpy() == 1, g[f"L{L}/ok"]), multi
 
 
 def test_decode_with_validator_vs_reference(engine):
