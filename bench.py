@@ -5,40 +5,40 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts N rank processes itself -- fresh children,
-before anything in the parent touches the GPU -- and fails loudly when fewer than N devices are visible.
+before anything in the parent touches the GPU -- polls all of them, and tears the job down on the first failure.
 
-Headline (`value`): one step = one pass of the receive hot path over one batch of synthetic frame records that is
-already resident in HBM: band-pass + 63-chip NCC + median/MAD threshold + NMS -> _llr (variant 0, known start /
-counter) -> Polar(1024,448) SCL-8 (validator None).  Workload = BASELINE config 2 (C2): 1 024 clean 1215-sample
-float32 frames per GPU, key 0xAA*32, ctr = i, payload RNG seed 20260101; for N > 1 every rank decodes its own
-1 024-frame shard of the counter range [0, 1024 N) (weak scaling); rank 0 derives the key/PN schedule and broadcasts
-it once over RCCL before the timed region; the data path has no collective.  Steps are streamed through
-echoseal_amd.engine.DecodePipeline: by default its grouped arrangement (--group 16: the front ends of 16 consecutive batches
-on four HIP streams fill one LLR buffer and ONE list-decoder launch -- one lane per path, eight frames per wave -- decodes
-the group; the last, possibly incomplete, group is decoded inside the timed region), or --group 0: seven whole-chain lanes.
+Headline (`value`): BASELINE config 3 (C3), the largest single-GPU configuration.  One step = one pass of the receive hot
+path over one batch of 65 536 synthetic windows per GPU, already resident in HBM: each window is 2 048 float32 samples
+holding one frame (ctr = i, key 0xAA*32) resampled by U[0.95, 1.05], at a uniform offset, in AWGN at -15 dB;
+band-pass -> fused sync (float32 NCC screen in LDS + exact median/MAD threshold + NMS / top-5, one kernel) -> _llr (variant 0)
+at the DETECTED peak -> Polar(1024,448) SCL-8 (validator None) -> candidate selection.  One window = one frame record, so
+`value` is frames/s.  Steps alternate between two pipeline lanes (HIP streams), so that the front end of one step runs
+beside the list decoder of the other.  N > 1: weak scaling -- rank r decodes its own 65 536 windows (counters
+[r * 65 536, (r + 1) * 65 536)); rank 0 derives the key/PN schedule of all counters and broadcasts it once (RCCL) before the
+timed region; the data path has no collective.  At --steps 20 the timed region is ~0.5 s of steady work.
 
 Further driver-timed legs in the same JSON line (`legs`), each bracketed by barrier + synchronize like the headline:
-  c2_lanes  the headline's batches through the other arrangement (seven whole-chain lanes, one list-decoder launch per batch):
-       the latency-oriented side of the trade, so that the line carries both.
-  c3   BASELINE config 3 on one GPU: 65 536 windows of 2 048 samples (frame resampled +-5 %, random offset, AWGN at
-       -15 dB), end to end: band-pass -> fused sync (float32 correlation row in LDS + exact threshold / peaks, one kernel) ->
-       _llr at the DETECTED peak -> SCL-8 -> selection.
-  c3_unfused  the same pass with the correlation row going through HBM (es_xcorr32_batch -> es_pick_exact_batch): identical
-       results; `roofline` is the stand-alone correlation kernel INSIDE this leg (HIP events on its launch stream).
-  c4   BASELINE config 4, strong scaling: 2^20 frames in total, ctr 0 .. 2^20-1, sharded contiguously over the N
-       ranks; rank 0 derives the whole key/PN schedule (153 B per counter = 160 MB) and broadcasts it (RCCL); every
-       rank streams its shard through the path in 131 072-frame chunks.  A checksum over (frame index, payload, ok) is
-       summed over ranks: it is the same number at every N.
-  c5   BASELINE config 5 SURROGATE (no MP3 codec in the image -- see echoseal_amd/workloads.lossy_channel; NOT MP3):
-       list size swept over 1/4/8/16, payload bit error rate and frames/s.
+  c2        BASELINE config 2: batches of 1 024 clean 1215-sample frames through the grouped streaming pipeline (the front ends of
+            16 batches on four streams fill one LLR buffer, one list-decoder launch per group), --c2-steps batches.
+  c2_lanes  the same batches through seven whole-chain lanes (one list-decoder launch per batch): rows within ~3 ms of submission.
+  c2_single one 1 024-frame batch alone, submission to completion (latency, not throughput).
+  c3_unfused the headline's pass with the correlation row going through HBM (es_xcorr32_batch -> es_pick_exact_batch): identical
+            results; `roofline` is the stand-alone correlation kernel INSIDE this leg (HIP events on its launch stream).
+  c4        BASELINE config 4, strong scaling: 2^20 frames in total, ctr 0 .. 2^20-1, sharded contiguously over the N ranks; rank 0
+            derives the whole schedule (153 B per counter = 160 MB) and broadcasts it; a checksum over (frame index, payload, ok,
+            sync offset) summed over ranks is the same number at every N.
+  c5        BASELINE config 5 SURROGATE (no MP3 codec in the image -- echoseal_amd/workloads.lossy_channel; NOT MP3):
+            list size swept over 1/4/8/16, payload bit error rate and frames/s.
 
 Extra objects:
-  roofline      es_xcorr32_kernel<17,2048> in the timed c3_unfused leg: algorithmic bytes per launch (16 136 B per 2 048-sample
-                window) / mean launch duration, against the 8 TB/s HBM peak; `traffic` from the committed PMC passes.
-  roofline_fused  the fused sync kernel in the timed c3 leg (8 192 + 150 B per window): LDS- and float64-bound, reported for completeness.
-  roofline_scl  the kernel that dominates the time (list decoder): vector instructions per frame (PMC, profiles/) x
-                frames/s against the FP64 vector issue peak.
-  cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") timed on this host (rank 0, N = 1 only).
+  roofline      es_xcorr32_kernel<17,2048> -- the kernel north_star grades against the HBM roofline -- in the timed c3_unfused leg:
+                algorithmic bytes per launch (16 136 B per window, SURVEY.md section 8d) / mean launch duration against 8 TB/s;
+                `traffic` from the committed PMC passes.  NOT on the headline path (the product's sync is the fused kernel): labelled so.
+  roofline_fused  the fused sync kernel inside the timed headline steps (8 192 + 150 B per window): LDS- and float64-bound.
+  roofline_scl  the kernel that dominates the time (list decoder, ~88 % of a step), at the HEADLINE's own rate: vector instructions,
+                float64 instructions and HBM-side bytes per frame from the committed PMC passes (profiles/r03_scl_pmc.json).
+  cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") timed on this host on a bounded sample of the headline's
+                windows (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -52,51 +52,51 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The streaming pipeline runs on 6-7 HIP streams; the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
-# (default 4), and streams that share a queue serialise.  Must be set before HIP starts.
+# The pipelines run on up to eight HIP streams; the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4), and streams that share a queue serialise.  Must be set before HIP starts (echoseal_amd.engine does the same on import).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 KEY = b"\xAA" * 32
-XCORR_BYTES_PER_FRAME = 4 * 1215 + 4 * (1215 - 62)        # 9 472 B
-XCORR_BYTES_PER_WINDOW = 4 * 2048 + 4 * (2048 - 62)       # 16 136 B
-FUSED_BYTES_PER_FRAME = 4 * 1215 + 150                      # fused sync: samples in, thr / peaks / npeaks / flag out
+XCORR_BYTES_PER_WINDOW = 4 * 2048 + 4 * (2048 - 62)       # SURVEY.md section 8(d): 16 136 B
+FUSED_BYTES_PER_WINDOW = 4 * 2048 + 150                    # fused sync: samples in, thr / peaks / npeaks / flag out
+SCL_BYTES_PER_FRAME = 4096 + 520                           # list decoder: LLRs in, <= 8 x (55 + 8 + 1) + hard decision out
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8.0 TB/s spec
-# FP64 vector issue peak: 78.6 TFLOP/s (spec) = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz, i.e. one wave64
-# FP64-class instruction per 4 cycles and SIMD -> 1024 SIMDs x 0.6 G = 614.4 G wave-instructions/s
+# FP64 vector peak: 78.6 TFLOP/s (spec) = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz, i.e. one wave64 float64 instruction per
+# 4 cycles and SIMD -> 1024 SIMDs x 0.6 G = 614.4 G wave-instructions/s
 FP64_ISSUE_PEAK_GWIPS = 256 * 4 * 2.4 / 4.0
+CLOCK_GHZ = 2.4
+N_SIMD = 1024
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=480)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=1024, help="frame records per GPU per step (C2 = 1024)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=65536, help="C3 windows per GPU per step (BASELINE config 3 = 65 536)")
     ap.add_argument("--list-size", type=int, default=8)
-    ap.add_argument("--legs", default="auto", help="comma list of c3,c4,c5 (auto: all at N = 1, c3 + c4 at N > 1; none: headline only)")
-    ap.add_argument("--c3-windows", type=int, default=65536)
-    ap.add_argument("--c3-steps", type=int, default=8)
+    ap.add_argument("--legs", default="auto", help="comma list of c2,c2_lanes,c3_unfused,c4,c5 (auto: all at N = 1, c2 + c4 at N > 1; none: headline only)")
+    ap.add_argument("--big-lanes", type=int, default=2, help="pipeline lanes of the headline and of the c4 leg (launches of 65 536 records)")
+    ap.add_argument("--frames", type=int, default=1024, help="frame records per batch of the c2 legs (C2 = 1024)")
+    ap.add_argument("--c2-steps", type=int, default=480)
+    ap.add_argument("--group", type=int, default=16, help="c2: batches per list-decoder launch of the grouped pipeline")
+    ap.add_argument("--front-lanes", type=int, default=4, help="c2: front-end streams of the grouped pipeline")
+    ap.add_argument("--scl-streams", type=int, default=2, help="c2: list-decoder streams of the grouped pipeline")
     ap.add_argument("--c4-frames", type=int, default=1 << 20, help="total frames of the strong-scaling leg (all ranks together)")
     ap.add_argument("--c4-chunk", type=int, default=65536)
-    ap.add_argument("--big-lanes", type=int, default=2, help="pipeline lanes of the c3 / c4 legs (launches of 65 536 records)")
     ap.add_argument("--c5-frames", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on fewer GPUs)")
-    ap.add_argument("--scl-streams", type=int, default=2, help="list-decoder streams (= batches in flight) of the pipeline")
-    ap.add_argument("--depth", type=int, default=0, help="batches in flight (0: = --scl-streams)")
-    ap.add_argument("--no-side-stream", action="store_true", help="front-end / list-decoder arrangement: LLR on the front-end stream")
-    ap.add_argument("--lanes", type=int, default=7, help="pipeline as K independent whole-chain lanes (0: front end + list-decoder streams)")
-    ap.add_argument("--group", type=int, default=16, help="batches per list-decoder launch (grouped pipeline: --front-lanes front streams, --scl-streams decoder streams, one lane per path); 0 = the whole-chain lanes of --lanes")
-    ap.add_argument("--front-lanes", type=int, default=4, help="front-end streams of the grouped pipeline")
-    ap.add_argument("--scl-multi", type=int, default=1, help="es_set_option scl_multi for the pipelined headline: -1 auto, 0 one frame per wave, 1 several")
     return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------ self-launch
-def launch_ranks(a) -> int:
+def launch_ranks(a, *, poll_s: float = 0.05) -> int:
     """Parent of an N > 1 run started without a launcher: spawn N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment) and pass rank 0's JSON line through.  The parent never initialises the GPU
-    (torch.cuda.device_count() does not, on this image), and the children are new processes, not re-execs."""
+    (torch.cuda.device_count() does not, on this image), and the children are new processes, not re-execs.
+    ALL children are polled: the first non-zero exit tears the job down (a dead rank leaves its peers waiting in a collective
+    until RCCL's own timeout) and becomes the parent's exit code."""
     import torch
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and ndev < a.gpus:
@@ -112,51 +112,66 @@ def launch_ranks(a) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
-            if rc:
-                break
+        live = set(range(a.gpus))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    rc = abs(code) or 1
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other {len(live)} rank(s)", file=sys.stderr)
+                    break
+            if live and rc == 0:
+                time.sleep(poll_s)
     finally:
-        for p in procs:                      # a failed rank leaves its peers waiting in a collective: end exactly those
+        for p in procs:                      # end exactly the processes started here
             if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
                 p.kill()
     return rc
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_worker(args):
-    """Decode a slice of frames `reps` times with the CPU oracle (one process = one core)."""
+    """Decode a slice of records `reps` times with the CPU oracle (one process = one core)."""
     import numpy as np
-    frames, band, pn, L, reps = args
+    frames, band, pn, L, reps, start = args
     from echoseal_amd.tables import pack_tables
     from oracle import oracle as O
     ba, tpl, taps, ntaps, _ = pack_tables()
     for _ in range(reps):
         for i in range(frames.shape[0]):
             b = band[i]
-            O.decode_frame(frames[i], ba[b], tpl[b], taps[b, :ntaps[b]], np.unpackbits(pn[i])[:1215], L=L)
+            O.decode_frame(frames[i], ba[b], tpl[b], taps[b, :ntaps[b]], np.unpackbits(pn[i])[:1215], L=L, start=start)
     return frames.shape[0] * reps
 
 
-def cpu_baseline(frames, band, pn, L, budget_s=15.0):
+def cpu_baseline(frames, band, pn, L, *, start, what, budget_s=15.0):
     import multiprocessing as mp
     from oracle import oracle as O
     O.build()
     cores = max(1, min(os.cpu_count() or 1, 16))
     t0 = time.perf_counter()
-    _cpu_worker((frames[:8], band[:8], pn[:8], L, 1))
+    _cpu_worker((frames[:8], band[:8], pn[:8], L, 1, start))
     per_frame = (time.perf_counter() - t0) / 8
     n = frames.shape[0] - frames.shape[0] % cores
     reps = max(1, int(round(budget_s * cores / max(per_frame * n, 1e-9))))     # ~budget_s of CPU work per core
-    chunks = [(frames[i:n:cores], band[i:n:cores], pn[i:n:cores], L, reps) for i in range(cores)]
+    chunks = [(frames[i:n:cores], band[i:n:cores], pn[i:n:cores], L, reps, start) for i in range(cores)]
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         t0 = time.perf_counter()
         done = sum(pool.map(_cpu_worker, chunks))
         dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the {frames.shape[0]} workload frames x {reps} passes = {done} decodes, oracle/c "
-                      f"(C restatement of the reference: sync + _llr + SCL-{L}), {cores} processes x 1 thread, {dt:.1f} s"}
+            "sample": f"{n} {what} x {reps} passes = {done} decodes, oracle/c (C restatement of the reference: sync + _llr + SCL-{L}), "
+                      f"{cores} processes x 1 thread, {dt:.1f} s"}
 
 
 def _profile_json(name):
@@ -169,6 +184,7 @@ def _profile_json(name):
 
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(a) -> None:
+    import gc
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -178,19 +194,21 @@ def run_rank(a) -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("ES_BENCH_FAIL_RANK") == str(rank):                      # (tests: a rank that dies before the first collective)
+        raise SystemExit(f"rank {rank}: failure injected by ES_BENCH_FAIL_RANK")
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and local >= ndev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) are visible")
-    if a.backend != "nccl":
-        local = local % max(1, ndev)                           # rehearsal: several ranks may share a GPU
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+    if a.backend != "nccl":
+        local = local % max(1, ndev)                           # rehearsal: several ranks may share a GPU
+        if world > 1:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)       # (the rendezvous needs no device)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and a.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,100 +225,203 @@ def run_rank(a) -> None:
 
     from echoseal_amd.dist import broadcast_schedule, build_schedule, shard_range, split_schedule
     from echoseal_amd.embedder import WatermarkEmbedder, synthetic_payloads
-    from echoseal_amd.engine import DecodePipeline, RxEngine
+    from echoseal_amd.engine import DecodePipeline, RxEngine, pipeline_streams
     from echoseal_amd import workloads as WL
 
-    legs = {"auto": ["c2_lanes", "c3", "c4", "c5"] if world == 1 else ["c3", "c4"], "none": []}.get(a.legs, a.legs.split(","))
+    legs = {"auto": ["c2", "c2_lanes", "c3_unfused", "c4", "c5"] if world == 1 else ["c2", "c4"], "none": []}.get(a.legs, a.legs.split(","))
     L = a.list_size
     eng = RxEngine(local, list_size_max=max(16, L))
-
-    # ============================================================ headline: C2, weak scaling
-    B = a.frames
-    total = B * world
-    lo, hi = shard_range(total, rank, world)
     tx = WatermarkEmbedder(KEY)
-    ctrs = list(range(lo, hi))
-    frames_h = tx.make_frames(ctrs, synthetic_payloads(tx.sec, ctrs))       # each rank synthesises its own frames
-    sched = build_schedule(KEY, range(total)) if rank == 0 else None
-    sched_d = broadcast_schedule(sched, total, dev)                           # the one collective (RCCL broadcast)
-    pn_d, band_d = split_schedule(sched_d, lo, hi)
-    frames_d = torch.from_numpy(frames_h).to(dev)
+    # Eight hardware queues: every pipeline of this process runs on the SAME seven streams (four front-end streams at high priority,
+    # two list-decoder / big-launch streams, one spare for the seven-lane leg)
+    front_streams = pipeline_streams(dev, a.front_lanes, priority=-1)
+    back_streams = pipeline_streams(dev, max(a.scl_streams, a.big_lanes))
+    out_legs = {}
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    # A step = one batch through the whole hot path.  Batches are independent, so the engine's streaming pipeline
-    # (echoseal_amd.engine.DecodePipeline) keeps two in flight: the front end of batch k+2 starts when batch k leaves,
-    # beside the list decoder of batch k+1.  Every step's outputs are complete at the final sync.
-    pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, depth=a.depth or None, lanes=a.front_lanes if a.group else a.lanes,
-                          side_stream=not a.no_side_stream, group=a.group)
-    if not a.group:
-        for e in pipe.scl_engs:
-            e.set_option("scl_multi", a.scl_multi)
+    # ============================================================ headline: C3, weak scaling
+    Bw = a.windows
+    total = Bw * world
+    lo, hi = shard_range(total, rank, world)                   # this rank's counters
+    # the key/PN schedule of ALL counters comes from rank 0 (derived on its GPU), one broadcast before the timed region
+    tb = time.perf_counter()
+    sched = torch.empty((total, 153), dtype=torch.uint8, device=dev)
+    if rank == 0:
+        p, b = eng.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=total)
+        sched[:, :152] = p; sched[:, 152] = b
+        del p, b
+    if world > 1:
+        dist.broadcast(sched, src=0)
+    barrier()
+    bcast_s = max_over_ranks(time.perf_counter() - tb)
+    pn3, band3 = split_schedule(sched, lo, hi)
+    del sched
+    parts = []
+    for c0 in range(0, Bw, 16384):                             # input synthesis on the device: this rank's clean frames ...
+        parts.append(eng.synthetic_frames(KEY, lo + c0, min(16384, Bw - c0))[0])
+    clean = torch.cat(parts); del parts
+    win, off = WL.c3_windows_device(clean, seed=34 + rank)     # ... resampled, offset, in noise
+    del clean
 
-    time_sync_launch = "c3" not in legs          # (HIP events around the sync launch of every step only when no c3 leg supplies the roofline objects)
+    pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=back_streams[:a.big_lanes])
+    for e in pipe3.lane_engs:                                   # kernels by launch size: 65 536 records -> one lane per path
+        e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
+    ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
-    def step(k=None):
-        sync_res, _llr, res, _done = pipe.submit(frames_d, band_d, pn_d, xcorr_events=None if (k is None or not time_sync_launch) else ev[k], inputs_ready=True)   # (resident since long before the clock starts)
-        return res, sync_res.peaks, sync_res.npeaks
+    def c3_step(k=None):
+        sy, _llr, scl, _done = pipe3.submit(win, band3, pn3, start="peak", select=True, xcorr_events=None if k is None else ev3[k])
+        return sy, scl
 
-    # Untimed preparation: every stream / context / kernel instantiation of the pipeline runs at least once and the group
-    # buffers exist before the clock starts (first launches allocate scratch and upload code; the W warm-up steps alone would
-    # leave some lanes and the full-size group launch cold), then the W warm-up steps the contract asks for.
-    for _ in range((len(pipe.backs) + 1) * a.group if a.group else 2 * a.lanes if a.lanes else 2 * a.scl_streams):
-        step()
-    pipe.synchronize(); torch.cuda.synchronize()
+    # Untimed preparation: every lane's context / kernels run once before the clock starts (first launches allocate and upload
+    # code), then the W warm-up steps the contract asks for.
+    for _ in range(a.big_lanes):
+        c3_step()
+    torch.cuda.synchronize()
     for _ in range(a.warmup):
-        step()
-    pipe.synchronize(); torch.cuda.synchronize()
-    lat = []                                   # latency of ONE batch with nothing else in flight, with the list decoder the library
-    for e in pipe.scl_engs:                    # picks for a lone 1 024-frame batch (one frame per wave); same streams as the pipeline
-        e.set_option("scl_multi", -1)          # (an extra stream would oversubscribe the eight hardware queues; grouped pipeline: already so)
-    step(); pipe.synchronize(); torch.cuda.synchronize()
-    for _ in range(3):
-        t1 = time.perf_counter()
-        step()
-        pipe.synchronize()                     # (grouped pipeline: decodes the one-batch group)
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - t1)
-    single_ms = 1e3 * min(lat)
-    if not a.group:
-        for e in pipe.scl_engs:
-            e.set_option("scl_multi", a.scl_multi)
-    import gc
-    gc.collect(); gc.disable()                  # (as timeit does: a collection inside a 10 ms timed region would be most of it)
+        c3_step()
+    torch.cuda.synchronize()
+    gc.collect(); gc.disable()
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        res, peaks, npeaks = step(k)
-    host_enqueue_s = time.perf_counter() - t0   # (reported: in a short run the start of the last launch hangs on it)
-    pipe.synchronize()                          # (grouped pipeline: decodes the last, possibly incomplete, group)
+        sy3, scl3 = c3_step(k)
+    host_enqueue_s = time.perf_counter() - t0
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     gc.enable()
-    xcorr_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if (a.steps and time_sync_launch) else float("nan")
-    ok_sync = bool(torch.all((npeaks >= 1) & (npeaks < 32)).item() and torch.all(peaks[:, 0] == 0).item())
-    if a.group:
+    fused_ms = float(np.mean([s.elapsed_time(e) for s, e in ev3])) if a.steps else float("nan")
+    payload3, ok3, _which3 = scl3.selected
+    if int((ok3 == -2).sum().item()) or int((scl3.ncand < 0).sum().item()):
+        raise SystemExit("list decoder reported undecoded records (ncand < 0)")
+    pk, npk = sy3.peaks, sy3.npeaks
+    found = int(((pk[:, :5] - off[:, None]).abs() <= 2).any(dim=1).sum().item())
+    head = {"listed": int((scl3.ncand > 0).sum().item()), "crc_ok": int((ok3 == 1).sum().item()),
+            "fallback": int(((npk >> 30) & 1).sum().item()), "exact_rows": int((sy3.flags != 0).sum().item())}
+    head_fps_per_gpu = Bw * a.steps / dt
+
+    # one sequential pass (default stream): stage breakdown, and the results every other arrangement must reproduce
+    def c3_seq(fused: bool, steps: int):
+        st = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(steps)]
+        xe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+        def one(k):
+            s = st[k] if k is not None else None
+            if s: s[0].record()
+            y, y32 = eng.bpf2(win, band3)
+            if s: s[1].record(); xe[k][0].record()
+            if fused:
+                thr, pk_, npk_, flags = eng.sync_fused(y, y32, band3)
+                if s: xe[k][1].record(); s[2].record()
+            else:
+                c32 = eng.xcorr32(y32, band3)
+                if s: xe[k][1].record(); s[2].record()
+                thr, pk_, npk_, flags = eng.pick_exact(c32, y, band3)
+            if s: s[3].record()
+            llr = eng.llr(y, band3, pn3, start=pk_[:, 0].clamp(min=0).contiguous())
+            if s: s[4].record()
+            scl = eng.scl(llr, list_size=L, skip_if_hard_ok=True)
+            if s: s[5].record()
+            payload, ok, _w = eng.select(scl)
+            if s: s[6].record()
+            return pk_, npk_, payload, ok
+        one(None); torch.cuda.synchronize()
+        barrier()
+        t = time.perf_counter()
+        for k in range(steps):
+            res = one(k)
+        barrier()
+        dts = max_over_ranks(time.perf_counter() - t)
+        names = ("bpf", "sync_fused" if fused else "xcorr32", "(in sync_fused)" if fused else "pick_exact", "llr", "scl", "select")
+        stage_ms = {n: float(np.mean([s[i].elapsed_time(s[i + 1]) for s in st])) for i, n in enumerate(names)}
+        return dts, float(np.mean([s.elapsed_time(e) for s, e in xe])), stage_ms, res
+
+    eng.set_option("scl_multi", -1); eng.set_option("scl_lane_slab", 1)
+    _dts, _x, stage_ms, (pk_s, npk_s, payload_s, ok_s) = c3_seq(True, 1)
+    same_as_seq = bool(torch.equal(pk, pk_s) and torch.equal(npk, npk_s) and torch.equal(payload3, payload_s) and torch.equal(ok3, ok_s))
+
+    # ============================================================ leg c3_unfused: the screen through HBM (the `roofline` kernel)
+    roof = None
+    if "c3_unfused" in legs:
+        nu = 3
+        dtu, x_ms, stage_u, (pk2, npk2, payload2, ok2) = c3_seq(False, nu)
+        same = bool(torch.equal(pk_s, pk2) and torch.equal(npk_s, npk2) and torch.equal(payload_s, payload2) and torch.equal(ok_s, ok2))
+        ach = XCORR_BYTES_PER_WINDOW * Bw / (x_ms * 1e-3) / 1e9
+        pmc = (_profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch", {})
+        roof = {"kernel": "es_xcorr32_kernel<17,2048> (es_xcorr32_batch: the stand-alone correlation kernel north_star grades against HBM)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc.get("hbm_bytes_per_launch") if Bw == 65536 else None,
+                "traffic_source": "rocprofv3 --pmc passes committed as profiles/r02_xcorr32_pmc_traffic.json (same launch shape; not re-measured by this run)",
+                "launch_ms": x_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_WINDOW * Bw,
+                "on_headline_path": False,
+                "where": f"HIP events around the launch inside the timed c3_unfused leg ({nu} steps); the headline's sync is the fused kernel "
+                         "(roofline_fused), which keeps this row in LDS -- this kernel is the es_xcorr32_batch entry point and the HBM-graded one"}
+        out_legs["c3_unfused"] = {"workload": "the headline's windows, sequential, sync = es_xcorr32_batch + es_pick_exact_batch (screen through HBM)",
+                                  "value": world * Bw * nu / dtu, "unit": "frames/s", "scaling": "weak", "steps": nu, "ms_per_step": 1e3 * dtu / nu,
+                                  "stage_ms": stage_u, "results_identical_to_the_headline": same}
+        del pk2, npk2, payload2, ok2
+    del pk_s, npk_s, payload_s, ok_s, sy3, scl3, payload3, ok3, pk, npk
+    win_h = band_h = pn_h = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        ns = min(Bw, 1024)
+        win_h, band_h, pn_h = win[:ns].cpu().numpy(), band3[:ns].cpu().numpy(), pn3[:ns].cpu().numpy()
+    del win, off, pn3, band3, pipe3
+    torch.cuda.empty_cache()
+
+    # ============================================================ legs c2 / c2_lanes / c2_single: 1 024-frame batches, streamed
+    if "c2" in legs or "c2_lanes" in legs:
+        B = a.frames
+        tot2 = B * world
+        lo2, hi2 = shard_range(tot2, rank, world)
+        ctrs = list(range(lo2, hi2))
+        frames_h = tx.make_frames(ctrs, synthetic_payloads(tx.sec, ctrs))       # each rank synthesises its own frames (host embedder)
+        sched2 = build_schedule(KEY, range(tot2)) if rank == 0 else None
+        sched2_d = broadcast_schedule(sched2, tot2, dev)
+        pn_d, band_d = split_schedule(sched2_d, lo2, hi2)
+        frames_d = torch.from_numpy(frames_h).to(dev)
+    if "c2" in legs:
+        pipe = DecodePipeline(eng, list_size=L, scl_streams=a.scl_streams, lanes=a.front_lanes, group=a.group,
+                              streams=(front_streams, back_streams[:a.scl_streams]))
+
+        def step():
+            sync_res, _llr, res, _done = pipe.submit(frames_d, band_d, pn_d, inputs_ready=True)   # (resident since long before the clock starts)
+            return res, sync_res.peaks, sync_res.npeaks
+        for _ in range((len(pipe.backs) + 1) * a.group):        # every stream / context / kernel instantiation once, group buffers exist
+            step()
+        pipe.synchronize(); torch.cuda.synchronize()
+        lat = []                                                # one batch alone: a group of one is decoded by the kernel the library picks for 1 024 frames
+        step(); pipe.synchronize(); torch.cuda.synchronize()
+        for _ in range(3):
+            t1 = time.perf_counter()
+            step()
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        gc.collect(); gc.disable()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(a.c2_steps):
+            res, peaks, npeaks = step()
+        pipe.synchronize()                                      # (decodes the last, possibly incomplete, group inside the timed region)
+        barrier()
+        dt2 = max_over_ranks(time.perf_counter() - t2)
+        gc.enable()
+        ok_sync = bool(torch.all((npeaks >= 1) & (npeaks < 32)).item() and torch.all(peaks[:, 0] == 0).item())
         res = res.result()
-    listed = int((res.ncand > 0).sum().item())
-    del res, peaks, npeaks
-    pipe.synchronize()
-
-    out_legs = {}
-    # the legs' pipelines run on the headline pipeline's streams: more than GPU_MAX_HW_QUEUES live streams would share hardware queues
-    big_streams = (list(pipe.backs) + list(pipe.lane_streams if a.group or a.lanes else []))[:a.big_lanes]
-    if len(big_streams) < a.big_lanes:
-        big_streams = None
-
-    # ============================================================ leg c2_lanes: the headline's batches through the OTHER arrangement
-    if "c2_lanes" in legs and a.group:
-        # seven whole-chain lanes (no grouping: every batch has its own list-decoder launch, rows within ~3 ms of submission):
-        # the latency-oriented arrangement, timed on the same frames so that the line carries both sides of the trade
-        st7 = (list(pipe.lane_streams) + list(pipe.backs))[:7]
-        st7 += [torch.cuda.Stream(dev) for _ in range(7 - len(st7))]
+        out_legs["c2"] = {"workload": f"C2: batches of {B} clean 1215-sample float32 frames per GPU (ctr = i, payload seed 20260101), sync + _llr(variant 0, start 0) + SCL-{L}; "
+                                      f"grouped pipeline: the front ends of {a.group} batches on {pipe.lanes} streams fill one LLR buffer, one list-decoder launch per group on one of "
+                                      f"{len(pipe.backs)} streams, the last (incomplete) group decoded inside the timed region",
+                          "value": tot2 * a.c2_steps / dt2, "unit": "frames/s", "scaling": "weak", "steps": a.c2_steps, "ms_per_step": 1e3 * dt2 / a.c2_steps,
+                          "timed_region_ms": 1e3 * dt2, "sync_offsets_ok": ok_sync, "frames_through_list_decoder": int((res.ncand > 0).sum().item())}
+        out_legs["c2_single"] = {"workload": "one C2 batch alone, submit -> complete (host clock, minimum of 3)", "value": 1e3 * min(lat), "unit": "ms",
+                                 "higher_is_better": False}
+        del res, peaks, npeaks, pipe
+    if "c2_lanes" in legs:
+        st7 = (front_streams + back_streams)[:7]
+        st7 += pipeline_streams(dev, 7 - len(st7))
         pipe7 = DecodePipeline(eng, list_size=L, lanes=7, streams=st7)
         for e in pipe7.scl_engs:
             e.set_option("scl_multi", 1); e.set_option("scl_lanes", 4)
-        n7 = min(a.steps, 200)
-        for _ in range(max(a.warmup, 14)):                     # every lane's context at least twice before the clock starts
+        n7 = min(a.c2_steps, 200)
+        for _ in range(14):                                     # every lane's context at least twice before the clock starts
             pipe7.submit(frames_d, band_d, pn_d)
         pipe7.synchronize(); barrier()
         t7 = time.perf_counter()
@@ -308,116 +429,14 @@ def run_rank(a) -> None:
             _sy7, _l7, res7, _d7 = pipe7.submit(frames_d, band_d, pn_d)
         pipe7.synchronize(); barrier()
         dt7 = max_over_ranks(time.perf_counter() - t7)
-        out_legs["c2_lanes"] = {"workload": "C2 (the headline's batches) through seven whole-chain lanes instead of the grouped pipeline: one list-decoder launch "
-                                            "(several frames per wave, four lanes per path) per 1 024-frame batch",
-                                "value": total * n7 / dt7, "unit": "frames/s", "scaling": "weak", "steps": n7, "ms_per_step": 1e3 * dt7 / n7,
+        out_legs["c2_lanes"] = {"workload": "C2 batches through seven whole-chain lanes (one list-decoder launch -- several frames per wave, four lanes per path -- per "
+                                            "1 024-frame batch): rows within ~3 ms of submission",
+                                "value": tot2 * n7 / dt7, "unit": "frames/s", "scaling": "weak", "steps": n7, "ms_per_step": 1e3 * dt7 / n7,
                                 "frames_through_list_decoder": int((res7.ncand > 0).sum().item())}
         eng.set_option("scl_multi", -1); eng.set_option("scl_lanes", 0)
         del pipe7, res7
-
-    # ============================================================ leg c3 (one GPU): 65 536 jittered / noisy windows
-    roof_c3 = roof_fused = None
-    if "c3" in legs:                                       # (at N > 1 every rank runs the same windows: the leg reports rank 0's rate)
-        Bw = a.c3_windows
-        parts, pays = [], []
-        for c0 in range(0, Bw, 16384):
-            f, p = eng.synthetic_frames(KEY, c0, min(16384, Bw - c0))
-            parts.append(f); pays.append(p)
-        clean = torch.cat(parts); del parts
-        win, off = WL.c3_windows_device(clean)
-        del clean
-        pn3, band3 = eng.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=Bw)
-        ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.c3_steps)]
-        stage = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(a.c3_steps)]
-
-        def c3_step(k=None, fused=True):
-            st = stage[k] if k is not None else None
-            if st: st[0].record()
-            y, y32 = eng.bpf2(win, band3)
-            if st: st[1].record(); ev3[k][0].record()
-            if fused:                                            # correlation screen + exact picking in one kernel
-                thr, pk, npk, flags = eng.sync_fused(y, y32, band3)
-                if st: ev3[k][1].record(); st[2].record()
-            else:                                                # the screen through HBM: es_xcorr32_batch -> es_pick_exact_batch
-                c32 = eng.xcorr32(y32, band3)
-                if st: ev3[k][1].record(); st[2].record()
-                thr, pk, npk, flags = eng.pick_exact(c32, y, band3)
-            if st: st[3].record()
-            start = pk[:, 0].clamp(min=0).contiguous()
-            llr = eng.llr(y, band3, pn3, start=start)
-            if st: st[4].record()
-            scl = eng.scl(llr, list_size=L, skip_if_hard_ok=True)
-            if st: st[5].record()
-            payload, ok, which = eng.select(scl)
-            if st: st[6].record()
-            return pk, npk, flags, payload, ok
-
-        def c3_run(fused, steps):
-            c3_step(fused=fused); torch.cuda.synchronize()
-            barrier()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                res3 = c3_step(k, fused=fused)
-            barrier()
-            dt3 = max_over_ranks(time.perf_counter() - t0)
-            x_ms = float(np.mean([s.elapsed_time(e) for s, e in ev3[:steps]]))
-            names = ("bpf", "sync_fused" if fused else "xcorr32", "(in sync_fused)" if fused else "pick_exact", "llr", "scl", "select")
-            stage_ms = {n: float(np.mean([st[i].elapsed_time(st[i + 1]) for st in stage[:steps]])) for i, n in enumerate(names)}
-            return dt3, x_ms, stage_ms, res3
-
-        wl3 = (f"C3: {Bw} windows of 2048 float32 samples per GPU, one frame each (ctr = i, resampled by U[0.95,1.05] with linear interpolation, uniform "
-               f"offset, AWGN at -15 dB SNR), generated on the device; band-pass -> float32 NCC screen + exact median/MAD threshold + NMS/top-5 "
-               f"-> _llr at the detected peak -> SCL-{L} -> selection")
-        _dt_seq, xf_ms, stage_ms, (pk, npk, flags, payload, ok) = c3_run(True, 2)          # sequential pass: stage breakdown, reference results
-        # the timed c3 leg: the same pass through the lane pipeline -- step k on lane k mod 2, so that the front end of one
-        # step runs beside the list decoder of the other (the list decoder's blocks are not persistent: wave slots free up
-        # as it proceeds)
-        pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=big_streams)
-        for e in pipe3.lane_engs:                                # kernels by launch size: 65 536 records -> one lane per path
-            e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
-        def c3_lane_step():
-            sy, _llr, scl, _done = pipe3.submit(win, band3, pn3, start="peak", select=True)
-            return sy, scl
-        c3_lane_step(); c3_lane_step(); torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(a.c3_steps):
-            sy3, scl3 = c3_lane_step()
-        barrier()
-        dt3 = max_over_ranks(time.perf_counter() - t0)
-        same_lane = bool(torch.equal(sy3.peaks, pk) and torch.equal(sy3.npeaks, npk) and torch.equal(scl3.selected[0], payload) and torch.equal(scl3.selected[1], ok))
-        del pipe3, sy3, scl3
-        found = int(((pk[:, :5] - off[:, None]).abs() <= 2).any(dim=1).sum().item())
-        achf = (4 * 2048 + 150) * Bw / (xf_ms * 1e-3) / 1e9
-        roof_fused = {"kernel": "es_xcorr32_kernel<17,2048,FUSED> (es_sync_fused_batch: screen row kept in LDS, threshold and peaks settled in the same kernel)",
-                      "bound": "hbm", "achieved": achf, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achf / HBM_PEAK_GBS, "traffic": None,
-                      "launch_ms": xf_ms, "algorithmic_bytes_per_launch": (4 * 2048 + 150) * Bw,
-                      "note": "8 192 B of samples in + <= 150 B out per window (SURVEY 8d fused figure); this kernel is bound by LDS passes and "
-                              "float64 re-evaluations, not by HBM -- it exists to take 2 x 7 944 B per window of screen traffic and two launches away",
-                      "where": f"HIP events around the launch inside the timed c3 leg ({a.c3_steps} steps)"}
-        out_legs["c3"] = {"workload": wl3 + f" [sync: es_sync_fused_batch; steps alternate between {a.big_lanes} pipeline lanes]",
-                          "value": world * Bw * a.c3_steps / dt3, "unit": "windows/s", "scaling": "weak", "steps": a.c3_steps, "ms_per_step": 1e3 * dt3 / a.c3_steps,
-                          "stage_ms_one_step_alone": stage_ms, "results_identical_to_the_sequential_pass": same_lane,
-                          "records_settled_by_the_exact_float64_row": int((flags != 0).sum().item()),
-                          "windows_with_a_top5_peak_within_2_samples_of_the_true_offset": found,
-                          "fallback_records": int(((npk >> 30) & 1).sum().item())}
-        # the same pass with the screen going through HBM (es_xcorr32_batch + es_pick_exact_batch): the leg `roofline` is taken from
-        nu = max(2, min(3, a.c3_steps))
-        dtu, x_ms, stage_u, (pk2, npk2, flags2, payload2, ok2) = c3_run(False, nu)
-        same = bool(torch.equal(pk, pk2) and torch.equal(npk, npk2) and torch.equal(payload, payload2) and torch.equal(ok, ok2))
-        ach = XCORR_BYTES_PER_WINDOW * Bw / (x_ms * 1e-3) / 1e9
-        pmc = (_profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch", {})
-        roof_c3 = {"kernel": "es_xcorr32_kernel<17,2048> (es_xcorr32_batch: the stand-alone correlation kernel north_star grades against HBM)",
-                   "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch") if Bw == 65536 else None,
-                   "traffic_source": "rocprofv3 --pmc passes committed as profiles/r02_xcorr32_pmc_traffic.json (same launch shape; not re-measured by this run)",
-                   "launch_ms": x_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_WINDOW * Bw,
-                   "where": f"HIP events around the launch inside the timed c3_unfused leg ({nu} steps)"}
-        out_legs["c3_unfused"] = {"workload": wl3 + " [sync: es_xcorr32_batch + es_pick_exact_batch, screen through HBM]",
-                                  "value": world * Bw * nu / dtu, "unit": "windows/s", "scaling": "weak", "steps": nu, "ms_per_step": 1e3 * dtu / nu, "stage_ms": stage_u,
-                                  "results_identical_to_c3": same}
-        del pk2, npk2, flags2, payload2, ok2
-        del win, off, pn3, band3, pk, npk, flags, payload, ok
+    if "c2" in legs or "c2_lanes" in legs:
+        del frames_d, pn_d, band_d
         torch.cuda.empty_cache()
 
     # ============================================================ leg c4: 2^20 frames, strong scaling
@@ -425,9 +444,8 @@ def run_rank(a) -> None:
         T4 = a.c4_frames
         lo4, hi4 = shard_range(T4, rank, world)
         n4 = hi4 - lo4
-        # the key/PN schedule of ALL counters comes from rank 0 (derived on its GPU), one broadcast
         barrier()
-        tb = time.perf_counter()
+        tb4 = time.perf_counter()
         sched4 = torch.empty((T4, 153), dtype=torch.uint8, device=dev)
         if rank == 0:
             p, b = eng.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=T4)
@@ -436,7 +454,7 @@ def run_rank(a) -> None:
         if world > 1:
             dist.broadcast(sched4, src=0)
         barrier()
-        bcast_s = max_over_ranks(time.perf_counter() - tb)
+        bcast4_s = max_over_ranks(time.perf_counter() - tb4)
         pn4, band4 = split_schedule(sched4, lo4, hi4)
         del sched4
         frames4 = torch.empty((n4, 1215), dtype=torch.float32, device=dev)
@@ -447,8 +465,7 @@ def run_rank(a) -> None:
         ok4 = torch.empty(n4, dtype=torch.int8, device=dev)
         peak4 = torch.empty(n4, dtype=torch.int32, device=dev)
         chunk = max(1, min(a.c4_chunk, n4))
-
-        pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=big_streams)
+        pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=back_streams[:a.big_lanes])
         for e in pipe4.lane_engs:
             e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
 
@@ -463,24 +480,27 @@ def run_rank(a) -> None:
 
         c4_pass(limit=chunk * a.big_lanes)                 # warm-up: one chunk per lane
         barrier()
-        t0 = time.perf_counter()
+        t4 = time.perf_counter()
         c4_pass()
         barrier()
-        dt4 = max_over_ranks(time.perf_counter() - t0)
+        dt4 = max_over_ranks(time.perf_counter() - t4)
         idx = torch.arange(lo4, hi4, dtype=torch.int64, device=dev)
         w = torch.arange(1, 56, dtype=torch.int64, device=dev)
         cks = (((payload4.to(torch.int64) * w).sum(1) + 1000 * ok4.to(torch.int64) + 7 * peak4.to(torch.int64)) * (idx % 65521 + 1)).sum().reshape(1)
         good = (peak4 == 0).sum().reshape(1)
+        bad = (ok4 == -2).sum().reshape(1)
         if world > 1:
-            dist.all_reduce(cks); dist.all_reduce(good)
+            dist.all_reduce(cks); dist.all_reduce(good); dist.all_reduce(bad)
+        if int(bad.item()):
+            raise SystemExit("c4: list decoder reported undecoded records")
         out_legs["c4"] = {"workload": f"C4: {T4} clean 1215-sample frames in total (ctr 0..{T4 - 1}, generated on the device), sharded contiguously over "
                                       f"{world} rank(s); schedule (153 B/ctr) derived on rank 0 and broadcast; sync + _llr(start 0) + SCL-{L} + selection "
                                       f"in launches of {chunk} frames on {a.big_lanes} pipeline lanes",
                           "value": T4 / dt4, "unit": "frames/s", "scaling": "strong", "seconds": dt4, "frames_total": T4,
-                          "frames_per_rank": n4, "schedule_broadcast_s": bcast_s, "schedule_bytes": T4 * 153,
-                          "value_incl_broadcast": T4 / (dt4 + bcast_s), "checksum": int(cks.item()),
+                          "frames_per_rank": n4, "schedule_broadcast_s": bcast4_s, "schedule_bytes": T4 * 153,
+                          "value_incl_broadcast": T4 / (dt4 + bcast4_s), "checksum": int(cks.item()),
                           "frames_with_sync_offset_0": int(good.item())}
-        del frames4, payload4, ok4, peak4, pn4, band4
+        del frames4, payload4, ok4, peak4, pn4, band4, pipe4
         torch.cuda.empty_cache()
 
     # ============================================================ leg c5 (surrogate; one GPU): list-size sweep
@@ -488,65 +508,77 @@ def run_rank(a) -> None:
         out_legs["c5"] = c5_leg(eng, a, torch, np, WL)
 
     if rank == 0:
-        achieved = FUSED_BYTES_PER_FRAME * B / (xcorr_ms * 1e-3) / 1e9
+        achf = FUSED_BYTES_PER_WINDOW * Bw / (fused_ms * 1e-3) / 1e9
         out = {
             "metric": "watermark frames/sec decoded (sync+LLR+SCL-8) @ 48 kHz",
             "value": total * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2: {B} clean 1215-sample float32 frames per GPU, key 0xAA*32, ctr=i, "
-                                   f"payload seed 20260101; sync + _llr(variant 0, start 0) + SCL-{L}, validator None",
-                       "frames_per_gpu": B, "list_size": L, "frame_len": 1215, "fs": 48000,
+            "config": {"workload": f"C3: {Bw} windows of 2048 float32 samples per GPU and step, one frame each (key 0xAA*32, ctr = i, resampled by U[0.95,1.05] with linear "
+                                   f"interpolation, uniform offset, AWGN at -15 dB SNR; generated on the device); band-pass -> float32 NCC screen + exact median/MAD "
+                                   f"threshold + NMS / top-5 (one fused kernel) -> _llr(variant 0) at the detected peak -> SCL-{L} (validator None) -> selection",
+                       "windows_per_gpu_per_step": Bw, "window_len": 2048, "list_size": L, "frame_len": 1215, "fs": 48000,
                        "world_size": world, "backend": ("nccl (RCCL)" if a.backend == "nccl" else a.backend) if world > 1 else "none (single rank)",
-                       "sharding": f"{world} x {B} frames, schedule broadcast from rank 0",
-                       "pipelining": (f"grouped: the front ends (band-pass .. demodulator) of {a.group} consecutive batches run on {pipe.lanes} HIP streams and fill one LLR buffer, "
-                                      f"ONE list-decoder launch (one lane per path, 64/L frames per wave) decodes the group on one of {len(pipe.backs)} further streams; "
-                                      f"up to {len(pipe.backs) + 1} groups in flight, the last (incomplete) group is decoded inside the timed region") if a.group else
-                                     (f"{a.lanes} batches in flight (DecodePipeline, whole-chain lanes: batch k runs band-pass .. list decoder on HIP stream k mod {a.lanes}, "
-                                      f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')})") if a.lanes else
-                                     f"{a.scl_streams} batches in flight (DecodePipeline: front-end stream + {a.scl_streams} list-decoder streams)",
-                       "untimed_preparation": "every stream / context / kernel of the pipeline runs before the clock starts (first launches allocate scratch and upload code), "
-                                              "then the --warmup steps; the garbage collector is off inside the timed region",
+                       "sharding": f"{world} x {Bw} windows per step (rank r: counters [r*{Bw}, (r+1)*{Bw})); schedule of all {total} counters derived on rank 0, "
+                                   f"one broadcast before the timed region ({total * 153} B, {bcast_s:.4f} s incl. derivation)",
+                       "pipelining": f"steps alternate between {a.big_lanes} pipeline lanes (HIP streams, one context each): the front end of one step runs beside the "
+                                     f"list decoder of the other; one list-decoder launch of {Bw} frames per step (one lane per path, 64/L frames per wave)",
+                       "untimed_preparation": "one step per lane (first launches allocate scratch and upload code), then the --warmup steps; the garbage collector is off inside the timed region",
                        "host_enqueue_ms_of_the_timed_steps": 1e3 * host_enqueue_s, "timed_region_ms": 1e3 * dt,
-                       "single_batch_latency_ms": single_ms,
-                       "sync_offsets_ok": ok_sync, "frames_through_list_decoder": listed},
+                       "stage_ms_one_step_alone": stage_ms, "results_identical_to_a_sequential_pass": same_as_seq,
+                       "frames_through_list_decoder": head["listed"], "frames_with_crc_ok": head["crc_ok"],
+                       "windows_with_a_top5_peak_within_2_samples_of_the_true_offset": found, "fallback_records": head["fallback"],
+                       "records_settled_by_the_exact_float64_row": head["exact_rows"]},
             "legs": out_legs,
         }
-        c2_roof = {"kernel": "es_xcorr32_kernel<19,1215,FUSED> (es_sync_fused_batch on the 1 024-record launch)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": xcorr_ms,
-                   "algorithmic_bytes_per_launch": FUSED_BYTES_PER_FRAME * B,
-                   "where": "HIP events around the launch inside the timed headline steps (event to event, beside resident list decoders); "
-                            "a 5 MB launch is latency-bound and served from L2 / Infinity Cache"}
-        if roof_c3 is not None:
-            out["roofline"] = roof_c3
+        roof_fused = {"kernel": "es_xcorr32_kernel<17,2048,FUSED> (es_sync_fused_batch: screen row kept in LDS, threshold and peaks settled in the same kernel)",
+                      "bound": "hbm", "achieved": achf, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achf / HBM_PEAK_GBS,
+                      "traffic": ((_profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch_fused", {}).get("hbm_bytes_per_launch") if Bw == 65536 else None),
+                      "launch_ms": fused_ms, "algorithmic_bytes_per_launch": FUSED_BYTES_PER_WINDOW * Bw, "on_headline_path": True,
+                      "note": "8 192 B of samples in + <= 150 B out per window (SURVEY 8d fused figure); bound by LDS passes and float64 re-evaluations, not by HBM -- "
+                              "it exists to take 2 x 7 944 B per window of screen traffic and two launches away",
+                      "where": f"HIP events around the launch inside the timed headline steps ({a.steps} steps, beside the other lane's list decoder)"}
+        if roof is not None:
+            out["roofline"] = roof
             out["roofline_fused"] = roof_fused
         else:
-            out["roofline"] = c2_roof                     # no c3 leg in this run: the fused sync launch of the headline steps
-        scl_pmc = _profile_json("r02_scl_pmc.json") or {}
-        kname = "es_scl_wide_kernel<64,8>" if a.group else "es_scl_multi_kernel<8>" if (a.lanes and a.scl_multi == 1) else "es_scl_kernel<8>"
-        key = next((k for k in scl_pmc if k.startswith(kname)), None)
-        if key and L == 8:
-            vi = scl_pmc[key]["per_frame"]["valu_instructions"]
-            head_fps = (total / world) * a.steps / dt                              # per GPU
-            # the sustained rate of this kernel: the c4 leg when it ran (the same kernel on 65 536-frame launches for ~0.4 s; a 20-step
-            # headline is a 12 ms burst that is mostly pipeline fill and drain), else the headline
-            c4 = out_legs.get("c4") if a.group else None
-            fps = c4["value"] / world if c4 else head_fps
-            rate = vi * fps / 1e9
-            out["roofline_scl"] = {"kernel": kname + " (the dominant kernel by time: ~85-90 % of a step's GPU work)", "bound": "fp64 vector issue",
-                                   "achieved": rate, "peak": FP64_ISSUE_PEAK_GWIPS, "unit": "G wave-instructions/s", "frac": rate / FP64_ISSUE_PEAK_GWIPS,
-                                   "valu_wave_instructions_per_frame": vi,
-                                   "frames_per_s_used": fps, "frames_per_s_from": "leg c4 (per GPU)" if c4 else "the timed headline steps (per GPU)",
-                                   "frac_at_the_headline_rate": vi * head_fps / 1e9 / FP64_ISSUE_PEAK_GWIPS,
-                                   "how": "vector wave-instructions per frame (SQ_INSTS_VALU / frames, PMC pass committed as profiles/r02_scl_pmc.json, same kernel) "
-                                          "x frames/s per GPU; peak = 78.6 TFLOP/s FP64 vector = one wave64 instruction per 4 cycles on "
-                                          "each of 1 024 SIMDs at 2.4 GHz (PMC: 4.2 vector-unit cycles per instruction in this kernel); the kernel is not HBM- or "
-                                          "MFMA-bound (4 096 B in, <= 520 B out per frame)"}
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_h, band_d.cpu().numpy(), pn_d.cpu().numpy(), L)
+            out["roofline"] = roof_fused                  # no c3_unfused leg in this run: the sync kernel of the headline steps
+        scl_roof = scl_roofline(head_fps_per_gpu, out_legs.get("c4", {}).get("value", 0.0) / world if "c4" in out_legs else None, L)
+        if scl_roof:
+            out["roofline_scl"] = scl_roof
+        if win_h is not None:
+            out["cpu_baseline"] = cpu_baseline(win_h, band_h, pn_h, L, start="peak", what=f"of the {Bw} headline windows (2048 samples each)")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def scl_roofline(head_fps, c4_fps, L):
+    """roofline_scl at the headline's own per-GPU rate, from the committed counter passes of es_scl_wide_kernel<64,8>."""
+    pmc = _profile_json("r03_scl_pmc.json")
+    if not pmc or L != 8:
+        return None
+    pf = pmc["per_frame"]
+    vi, f64 = pf["valu_instructions"], pf["fp64_instructions"]
+    other = vi - f64 - pf.get("trans_f64_instructions", 0)
+    rate = vi * head_fps / 1e9
+    cyc = pmc.get("issue_cycles", {"fp64": 4.0, "trans_f64": 16.0, "other": 4.0})
+    busy_cycles_per_frame = f64 * cyc["fp64"] + pf.get("trans_f64_instructions", 0) * cyc["trans_f64"] + other * cyc["other"]
+    out = {"kernel": "es_scl_wide_kernel<64,8> (one lane per path; the dominant kernel by time: ~88 % of a step's GPU work)", "bound": "fp64 vector issue",
+           "achieved": rate, "peak": FP64_ISSUE_PEAK_GWIPS, "unit": "G wave-instructions/s", "frac": rate / FP64_ISSUE_PEAK_GWIPS,
+           "frames_per_s_used": head_fps, "frames_per_s_from": "the timed headline steps (per GPU)",
+           "frac_at_the_c4_rate": (vi * c4_fps / 1e9 / FP64_ISSUE_PEAK_GWIPS) if c4_fps else None,
+           "valu_wave_instructions_per_frame": vi, "fp64_wave_instructions_per_frame": f64,
+           "fp64_pipe_frac": (f64 * 4.0 + pf.get("trans_f64_instructions", 0) * 16.0) * head_fps / (N_SIMD * CLOCK_GHZ * 1e9),
+           "issue_slot_frac_mixed_ceiling": busy_cycles_per_frame * head_fps / (N_SIMD * CLOCK_GHZ * 1e9),
+           "issue_cycles_charged": cyc,
+           "traffic": pf.get("hbm_side_bytes"), "algorithmic_bytes_per_frame": SCL_BYTES_PER_FRAME,
+           "traffic_note": "bytes per frame through the L2's memory side (FETCH_SIZE x 2 for the 128-byte read requests + WRITE_SIZE; Infinity-Cache hits are counted): "
+                           "the tree levels kept in the scratch slab, not the 4.6 KB a frame brings and leaves",
+           "how": "per-frame counts from the rocprofv3 --pmc passes committed as profiles/r03_scl_pmc.json (same kernel, B = 65 536) x the headline's frames/s per GPU; "
+                  "`frac` charges every vector instruction 4 cycles (peak 78.6 TFLOP/s FP64 vector = one wave64 instruction per 4 cycles on each of 1 024 SIMDs at 2.4 GHz); "
+                  "`issue_slot_frac_mixed_ceiling` charges each class what tools/ub/ub_issue.hip measures at three waves per SIMD; `fp64_pipe_frac` counts only float64 arithmetic"}
+    return out
 
 
 def c5_leg(eng, a, torch, np, WL):

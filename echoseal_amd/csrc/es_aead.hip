@@ -196,10 +196,11 @@ __global__ __launch_bounds__(256) void es_select_kernel(AeadKey key, int use_key
         const uint32_t c = use_key ? ctr[f] : 0u;
         const uint8_t* src = hard_info + f * ES_INFO_BYTES;
         int which = -1, ok = 0;
-        if (hard_ok[f] && (!use_key || validate_blob(key, src, c, nullptr))) ok = 1;
+        const int n = ncand[f];
+        if (n < 0) ok = -2;                                        // the list decoder could not decode this record (es_scl_batch): nothing of its rows is defined
+        else if (hard_ok[f] && (!use_key || validate_blob(key, src, c, nullptr))) ok = 1;
         else {
-            const int n = ncand[f];
-            if (n <= 0) ok = -1;                                   // list loop was skipped: usage error, reported to the host
+            if (n == 0) ok = -1;                                   // list loop was skipped: usage error, reported to the host
             else {
                 int best_crc = -1, best_any = -1;
                 double best_any_m = __builtin_inf();
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void es_select_kernel(AeadKey key, int use_key
                 if (which >= 0) src = ci + (long long)which * ES_INFO_BYTES;
             }
         }
-        for (int k = 0; k < ES_INFO_BYTES; ++k) payload[f * ES_INFO_BYTES + k] = src[k];
+        for (int k = 0; k < ES_INFO_BYTES; ++k) payload[f * ES_INFO_BYTES + k] = (ok == -2) ? (uint8_t)0 : src[k];
         ok_out[f] = (int8_t)ok;
         which_out[f] = which;
     }

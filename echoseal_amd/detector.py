@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from ._native import NativeError
 from .crypto import SecureChannel
 from .polar_fast import N_DEFAULT
 from .primitives import InvalidTag
@@ -119,33 +120,39 @@ class WatermarkDetector:
                 continue
             for i, sc in zip(idx, self._scan_prepare([signals[i] for i in idx], order)):
                 scans[i] = sc
-        # decoding is stateless (the validator's verdict depends on blob and counter only; nonce bookkeeping happens on the host,
-        # in _accept): the candidates of ALL clips of a group and all their bands go through one demodulate + list-decode +
-        # validate batch, and the clips are then walked in order with the reference's early returns
-        decoded: dict[int, tuple] = {}
-        for (_size, _is_i16), idx in groups.items():
-            live = [i for i in idx if scans[i] is not None]
-            if not live:
-                continue
-            plans = {i: [self._scan_plan(scans[i], bi) for bi in range(len(order))] for i in live}
-            flat = [p for i in live for plan, _ in plans[i] for p in plan]
-            results = self._decode_pairs(scans[live[0]]["frames"], [p[0] for p in flat], [p[2] for p in flat]) if flat else []
-            at = 0
-            for i in live:
-                n = sum(len(plan) for plan, _ in plans[i])
-                decoded[i] = (plans[i], results[at:at + n])
-                at += n
+        # Decoding is stateless (the validator's verdict depends on blob and counter only; nonce bookkeeping happens on the host, in
+        # _accept), so it can be batched across clips; the WALK is clip by clip and band by band, in the reference's order with its
+        # early returns.  Band rank r of a clip is decoded when the walk first needs it, together with rank r of every later clip of
+        # the group whose earlier ranks are already known to hold no decodable blob at all (those clips are certain to reach rank r):
+        # one demodulate + list-decode + validate batch per band rank in the common cases, never the 4 x 400 candidates x 4 variants
+        # of every band of every clip up front.
+        plans: dict[int, list] = {i: [self._scan_plan(scans[i], bi) for bi in range(len(order))] for i in range(len(signals)) if scans[i] is not None}
+        cache: dict[tuple[int, int], list] = {}
+        group_of = {i: idx for idx in groups.values() for i in idx}
+
+        def hopeless(i: int, upto: int) -> bool:          # ranks < upto decoded and without a single blob: the clip will reach rank `upto`
+            return all((i, r) in cache and not any(b is not None for blobs in cache[(i, r)] for b in blobs) for r in range(upto))
+
+        def need(i: int, bi: int) -> list:
+            if (i, bi) not in cache:
+                batch = [i] + [j for j in group_of[i] if j > i and scans[j] is not None and (j, bi) not in cache and hopeless(j, bi)]
+                flat = [(j, p) for j in batch for p in plans[j][bi][0]]
+                res = self._decode_pairs_grouped([(scans[j]["frames"], p[0], p[2]) for j, p in flat]) if flat else []
+                at = 0
+                for j in batch:
+                    n = len(plans[j][bi][0])
+                    cache[(j, bi)] = res[at:at + n]
+                    at += n
+            return cache[(i, bi)]
+
         out = []
         for i in range(len(signals)):
             ok = False
             if scans[i] is not None:
-                plans_i, results = decoded[i]
-                at = 0
-                for bi, (plan, hdr_log) in enumerate(plans_i):
-                    if self._scan_replay(scans[i], bi, plan, hdr_log, results[at:at + len(plan)]):
+                for bi, (plan, hdr_log) in enumerate(plans[i]):
+                    if self._scan_replay(scans[i], bi, plan, hdr_log, need(i, bi) if plan else []):
                         ok = True
                         break
-                    at += len(plan)
             out.append(ok)
         return out
 
@@ -179,10 +186,10 @@ class WatermarkDetector:
 
     def _scan_plan(self, scan, bi: int):
         """The candidate (peak, counter) pairs of one band in the reference's try order (rtwm/detector.py:105-140):
-        -> (plan [(peak slot j, start, ctr)], header log of the peaks looked at)."""
+        -> (plan [(peak slot j, start, ctr, header-log index)], header log of the peaks looked at)."""
         band = scan["bands"][bi]
         sel = [int(j) for j in scan["sel"] if scan["rows"][j] == bi]       # this band's peaks, in peak order
-        plan: list[tuple[int, int, int]] = []
+        plan: list[tuple[int, int, int, int]] = []
         hdr_log = []
         tried = 0
         for j in sel:
@@ -206,20 +213,22 @@ class WatermarkDetector:
                         if choose_band(self._band_key, ctr) == band:
                             cands.append(ctr)
             for ctr in cands[:MAX_TRIES - tried]:
-                plan.append((j, start, ctr))
+                plan.append((j, start, ctr, len(hdr_log) - 1))              # (.., index of this peak's header decode in hdr_log)
             tried += len(cands[:MAX_TRIES - tried])
         return plan, hdr_log
 
     def _scan_replay(self, scan, bi: int, plan, hdr_log, results) -> bool:
         """Walk one band's decoded candidates as the reference does (early return, traces, nonce bookkeeping in _accept)."""
         band = scan["bands"][bi]
-        if self._hdr_trace is not None:
-            self._hdr_trace.extend(hdr_log)
-        for (j, start, ctr), blobs in zip(plan, results):
+        for (j, start, ctr, h), blobs in zip(plan, results):
             if self._trace is not None:
                 self._trace.append((int(band[0]), int(start), int(ctr)))
             if self._accept(blobs, ctr):
+                if self._hdr_trace is not None:                             # the reference decodes a peak's header when it reaches the peak:
+                    self._hdr_trace.extend(hdr_log[:h + 1])                 # peaks after the accepted one were never looked at
                 return True
+        if self._hdr_trace is not None:
+            self._hdr_trace.extend(hdr_log)
         return False
 
     def _scan_decide(self, scan, bi: int) -> bool:
@@ -231,20 +240,6 @@ class WatermarkDetector:
             return False
         results = self._decode_pairs(scan["frames"], [p[0] for p in plan], [p[2] for p in plan])
         return self._scan_replay(scan, bi, plan, hdr_log, results)
-
-    def _scan_decide_all(self, scan) -> bool:
-        """All bands of one clip: the candidates of every band go through ONE demodulate + list-decode + validate batch (decoding
-        is stateless; a band the reference would not have reached costs GPU time, never a different answer), then the bands
-        are walked in the reference's order with its early return -- results, traces and nonce bookkeeping as band by band."""
-        plans = [self._scan_plan(scan, bi) for bi in range(len(scan["bands"]))]
-        flat = [p for plan, _ in plans for p in plan]
-        results = self._decode_pairs(scan["frames"], [p[0] for p in flat], [p[2] for p in flat]) if flat else []
-        at = 0
-        for bi, (plan, hdr_log) in enumerate(plans):
-            if self._scan_replay(scan, bi, plan, hdr_log, results[at:at + len(plan)]):
-                return True
-            at += len(plan)
-        return False
 
     def verify_raw_frame(self, signal: np.ndarray) -> bool:
         signal = np.asarray(signal)
@@ -339,7 +334,32 @@ class WatermarkDetector:
         frames = self._dev(np.asarray(frame, dtype=np.float64).reshape(1, -1), np.float64)
         return self._decode_pairs(frames, [0] * len(ctrs), ctrs)
 
+    def _decode_pairs_grouped(self, triples) -> list[list[bytes | None]]:
+        """_decode_pairs for (frames tensor, row, ctr) triples that may come from several clips (each clip has its own
+        frames tensor): consecutive triples of one tensor go through one call."""
+        out: list = []
+        k = 0
+        while k < len(triples):
+            fr = triples[k][0]
+            m = k
+            while m < len(triples) and triples[m][0] is fr:
+                m += 1
+            out += self._decode_pairs(fr, [t[1] for t in triples[k:m]], [t[2] for t in triples[k:m]])
+            k = m
+        return out
+
     def _decode_pairs(self, frames, rows, ctrs) -> list[list[bytes | None]]:
+        """Chunked front of _decode_pairs_chunk: at most 2^18 list paths per variant and launch (1 024 pairs at the default
+        list size 256: cand_info of one chunk is 58 MB), so that a long candidate list never asks for gigabytes at once."""
+        cap = max(64, (1 << 18) // max(1, self._list_size))
+        if len(ctrs) <= cap:
+            return self._decode_pairs_chunk(frames, rows, ctrs)
+        out: list = []
+        for k in range(0, len(ctrs), cap):
+            out += self._decode_pairs_chunk(frames, rows[k:k + cap], ctrs[k:k + cap])
+        return out
+
+    def _decode_pairs_chunk(self, frames, rows, ctrs) -> list[list[bytes | None]]:
         """The same for (frame, counter) pairs: frames = device tensor [P, <=1215] float64, pair i = (frames[rows[i]], ctrs[i]).
         One batch: two demodulations (PN variants 0 / 1), one list decode of the 4 B sign / variant combinations, one
         validation + selection (es_select_batch with the AEAD key) -- no host round trip per candidate."""
@@ -362,6 +382,8 @@ class WatermarkDetector:
             # self._validator(ctr), without a Python callback per candidate
             payload, ok, _which = eng.select(res, key32=key, ctrs=torch.tensor(ctrs * 4, dtype=torch.int64))
             payload = payload.cpu().numpy(); ok = ok.cpu().numpy()
+            if (ok == -2).any():
+                raise NativeError("es_scl_batch: some candidate records were not decoded (no free scratch-slab slot)")
             return [[payload[v * B + i].tobytes() if ok[v * B + i] == 1 else None for v in range(4)] for i in range(B)]
         out = []
         for i, ctr in enumerate(ctrs):

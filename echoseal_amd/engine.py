@@ -14,6 +14,9 @@ sync + LLR (variant 0, known start/counter) + SCL-L.
 """
 from __future__ import annotations
 
+import os
+import warnings
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -21,6 +24,39 @@ import torch
 
 from . import _native as nat
 from .tables import pack_tables
+
+# The streaming pipelines run on up to eight HIP streams.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4) and streams that share a queue serialise: with the default, every arrangement with more than four streams is slower,
+# silently (a third of the grouped pipeline's rate).  The variable is read when HIP initialises, so it is set here when that has not
+# happened yet; DecodePipeline warns when more streams are alive than the budget this module could establish.
+HW_QUEUES_WANTED = 8
+if "GPU_MAX_HW_QUEUES" not in os.environ and not torch.cuda.is_initialized():
+    os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES_WANTED)
+_HWQ_ENV_AT_IMPORT = os.environ.get("GPU_MAX_HW_QUEUES")      # None: HIP was already up, without the variable
+_LIVE_STREAMS: "weakref.WeakSet" = weakref.WeakSet()           # streams made by DecodePipeline objects that are still alive
+
+
+def hw_queue_budget() -> int:
+    """Hardware queues the process's HIP streams are spread over, as far as this module can tell: GPU_MAX_HW_QUEUES as it stood
+    when the module was imported (set by the module itself if HIP had not started), else the runtime's default of 4."""
+    try:
+        return max(1, int(_HWQ_ENV_AT_IMPORT)) if _HWQ_ENV_AT_IMPORT is not None else 4
+    except ValueError:
+        return 4
+
+
+def pipeline_streams(device, n: int, priority: int = 0) -> list:
+    """n new HIP streams, counted against the hardware-queue budget (DecodePipeline makes its own through this; a process that builds
+    several pipelines makes the streams once and hands them to each: DecodePipeline(streams=...))."""
+    out = [torch.cuda.Stream(device, priority=priority) for _ in range(n)]
+    for st in out:
+        _LIVE_STREAMS.add(st)
+    if len(_LIVE_STREAMS) > hw_queue_budget():
+        warnings.warn(f"DecodePipeline: {len(_LIVE_STREAMS)} pipeline streams are alive but the HIP runtime has {hw_queue_budget()} hardware queues "
+                      f"(GPU_MAX_HW_QUEUES{'=' + _HWQ_ENV_AT_IMPORT if _HWQ_ENV_AT_IMPORT else ' was not set before HIP initialised'}): streams that share a "
+                      "queue serialise.  Set GPU_MAX_HW_QUEUES=8 before the first GPU call (importing echoseal_amd.engine first does it), "
+                      "and hand existing streams to further pipelines (streams=...).", RuntimeWarning, stacklevel=3)
+    return out
 
 
 def _ptr(t: torch.Tensor | None) -> int | None:
@@ -34,7 +70,15 @@ class SclResult:
     cand_info: torch.Tensor    # [B,L,55] uint8, ascending metric
     cand_metric: torch.Tensor  # [B,L] float64
     cand_ok: torch.Tensor      # [B,L] uint8
-    ncand: torch.Tensor        # [B] int32 (0 = list loop skipped)
+    ncand: torch.Tensor        # [B] int32 (0 = list loop skipped; < 0 = the kernel could not decode the record: see check())
+
+    def check(self) -> "SclResult":
+        """Raise if the list decoder reported records it could not decode (ncand < 0: a block found no free slot of the scratch
+        slab -- cannot happen while resident blocks <= slots, and must never pass silently).  Synchronises on the result."""
+        bad = int((self.ncand < 0).sum().item())
+        if bad:
+            raise nat.NativeError(f"es_scl_batch: {bad} record(s) were not decoded (no free scratch-slab slot); the candidate rows of those records are undefined")
+        return self
 
 
 @dataclass
@@ -51,6 +95,8 @@ class SyncResult:
 
 class RxEngine:
     def __init__(self, device: int | torch.device = 0, *, list_size_max: int = 32, fs: int = 48_000):
+        """list_size_max: the largest list `scl` will be asked for (sizes the list decoder's scratch: 0.4 GB, above 32 another 1.6 GB);
+        0 = a front-end engine (everything but `scl`, no list-decoder scratch): what a pipeline's band-pass / sync / demodulator streams use."""
         if not torch.cuda.is_available():
             raise nat.NativeError("RxEngine needs a ROCm GPU: torch.cuda.is_available() is False")
         self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
@@ -483,7 +529,8 @@ class DecodePipeline:
         further streams, at most `depth` batches in flight.
 
     Results are complete after `wait(result)` / `synchronize()`.  A process should keep at most GPU_MAX_HW_QUEUES (8) HIP
-    streams alive: pass `streams=` to build a further lanes pipeline on existing ones."""
+    streams alive: pass `streams=` (lanes: a list; grouped: (front-end streams, list-decoder streams)) to build a further pipeline on
+    existing ones; more live pipeline streams than hardware queues raises a RuntimeWarning (hw_queue_budget)."""
 
     def __init__(self, eng: "RxEngine", *, list_size: int = 8, scl_streams: int = 2, depth: int | None = None, lanes: int = 0,
                  side_stream: bool = True, group: int = 0, streams=None):
@@ -501,9 +548,14 @@ class DecodePipeline:
             self.lanes = max(1, int(lanes) or 4)
             nb = max(1, int(scl_streams))
             # the short front-end kernels get dispatch priority: they must slip in whenever list-decoder waves leave
-            self.lane_streams = [torch.cuda.Stream(dev, priority=-1) for _ in range(self.lanes)]
-            self.lane_engs = [eng] + [RxEngine(dev, list_size_max=8) for _ in range(self.lanes - 1)]
-            self.backs = [torch.cuda.Stream(dev) for _ in range(nb)]
+            # `streams` = (front-end streams, list-decoder streams) to run on instead of new ones
+            self.lane_streams = list(streams[0])[:self.lanes] if streams is not None else pipeline_streams(dev, self.lanes, priority=-1)
+            if len(self.lane_streams) != self.lanes:
+                raise ValueError("streams: one front-end stream per lane")
+            self.lane_engs = [eng] + [RxEngine(dev, list_size_max=0) for _ in range(self.lanes - 1)]     # front-end contexts: no list-decoder scratch
+            self.backs = list(streams[1])[:nb] if streams is not None else pipeline_streams(dev, nb)
+            if len(self.backs) != nb:
+                raise ValueError("streams: one list-decoder stream per scl_streams")
             self.scl_engs = [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in range(nb)]
             for e in self.scl_engs:                   # kernel by launch size: a full group runs one lane per path, a lone batch one frame per wave
                 e.set_option("scl_multi", -1); e.set_option("scl_lanes", 0); e.set_option("scl_lane_slab", 1)
@@ -512,10 +564,6 @@ class DecodePipeline:
             self._open = None
             self._k = self._g = 0
             self._flush_lanes = 0                     # (tests: 1 = one lane per path whatever the group's size)
-            # after an idle pipeline the first group of every decoder stream is 5/8 of a full one: a burst reaches all decoder
-            # streams sooner, and a list-decoder wave takes ~8 ms whatever its launch, so the start of the LAST launch of a
-            # burst is what its completion hangs on (a 20-batch burst as 10 + 10: 1.71 against 1.60 M frames/s as 16 + 4)
-            self._since_idle = 0
             return
         # `lanes` > 0: the other arrangement -- K independent lanes, each one HIP stream (= one hardware queue) with its
         # own context that runs the WHOLE chain of its batches (k, k+K, ...) in order; no cross-stream events at all.
@@ -524,7 +572,7 @@ class DecodePipeline:
             # (lane 0 on the caller's own stream was measured slower: 1.29 M against 1.43 M frames/s at 7 lanes)
             # `streams`: HIP streams to run the lanes on instead of new ones -- a process that builds several pipelines should hand
             # the same streams to each: beyond GPU_MAX_HW_QUEUES (8) live streams, streams share hardware queues and serialise
-            self.lane_streams = list(streams)[:self.lanes] if streams is not None else [torch.cuda.Stream(dev) for _ in range(self.lanes)]
+            self.lane_streams = list(streams)[:self.lanes] if streams is not None else pipeline_streams(dev, self.lanes)
             if len(self.lane_streams) != self.lanes:
                 raise ValueError("streams: one per lane")
             self.lane_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in range(self.lanes - 1)]
@@ -534,9 +582,9 @@ class DecodePipeline:
             self._k = 0
             return
         # the short front-end kernels get dispatch priority over the long-running list decoders
-        self.front = torch.cuda.Stream(dev, priority=-1)
-        self.side = torch.cuda.Stream(dev, priority=-1) if side_stream else self.front   # one hardware queue less without it
-        self.backs = [torch.cuda.Stream(dev) for _ in range(max(1, int(scl_streams)))]
+        self.front = pipeline_streams(dev, 1, priority=-1)[0]
+        self.side = pipeline_streams(dev, 1, priority=-1)[0] if side_stream else self.front   # one hardware queue less without it
+        self.backs = pipeline_streams(dev, max(1, int(scl_streams)))
         self.scl_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in self.backs[1:]]
         # Batches in flight = list-decoder streams: the front end of batch k waits for batch k-2 to leave, so it
         # runs while only ONE list decoder is resident (two of them fill every SIMD's register file and would
@@ -548,8 +596,8 @@ class DecodePipeline:
 
     def submit(self, frames: torch.Tensor, band: torch.Tensor, pn_rows: torch.Tensor, *,
                start: torch.Tensor | None = None, xcorr_events=None, select: bool = False, inputs_ready: bool = False):
-        """Enqueue one batch.  inputs_ready (grouped arrangement): skip the wait on the caller's stream -- for inputs known to be
-        complete on the device (10 us of host time per batch).  start: frame starts [B] (None = 0; "peak" = the first detected peak of each record, lanes only);
+        """Enqueue one batch.  inputs_ready (grouped arrangement): skip the wait on the caller's stream -- for INPUTS known to be
+        complete on the device (10 us of host time per batch; it covers the inputs only: the group's own buffers are ordered by the pipeline).  start: frame starts [B] (None = 0; "peak" = the first detected peak of each record, lanes only);
         select (lanes only): also run the candidate selection (es_select_batch, validator None) on the lane's stream --
         the result is attached to the returned SclResult as `.selected = (payload, ok, which)`."""
         eng = self.eng
@@ -629,9 +677,13 @@ class DecodePipeline:
             st.wait_stream(torch.cuda.current_stream(self.eng.device))
         if g.throttle is not None:
             st.wait_event(g.throttle)                                         # at most len(ring) groups in flight on the GPU
+        if g.llr is None:
+            g.allocate(st)                                                    # on THIS lane's stream: the block's earlier life is ordered before its writes
         if j not in g.lanes_used:
             g.lanes_used.add(j)
-            g.llr.record_stream(st)                                           # (allocated on the caller's stream, written here)
+            if st is not g.alloc_stream:
+                st.wait_event(g.alloc_ev)                                     # (a recycled block may still be in use by work queued on the allocating stream)
+                g.llr.record_stream(st)
         slot = g.count
         rows = g.llr[slot * B:(slot + 1) * B]
         with torch.cuda.stream(st):
@@ -670,9 +722,6 @@ class DecodePipeline:
             lp <<= 1
         # one lane per path once the group gives every SIMD a wave (launches of several groups overlap); a lone batch: the library's choice
         e.set_option("scl_lanes", 1 if (g.count * g.B * lp >= 64 * 1024 or self._flush_lanes == 1) else 0)
-        # the later launches of a burst run at a higher wave priority: a list-decoder wave takes ~8-10 ms whatever its launch, so a
-        # launch that starts 1-2 ms after its neighbour should not also finish 1-2 ms after it (steady state: every launch at 1)
-        e.set_option("scl_prio", min(1, g.order))                # (never above 1: the front-end kernels issue at 2 and 3)
         g.llr.record_stream(back)
         with torch.cuda.stream(back):
             g.scl = e.scl(g.llr[:g.count * g.B], list_size=self.list_size, skip_if_hard_ok=True)
@@ -693,7 +742,6 @@ class DecodePipeline:
                 self._flush(self._open)
             for st in self.lane_streams:
                 st.synchronize()
-            self._since_idle = 0
         if self.front is not None:
             self.front.synchronize(); self.side.synchronize()
         for b in self.backs:
@@ -706,17 +754,23 @@ class _Group:
     def __init__(self, pipe: DecodePipeline, B: int, select: bool, prev, device):
         self.pipe, self.B, self.select = pipe, B, select
         self.index = pipe._g
-        self.capacity = pipe.group if pipe._since_idle >= len(pipe.backs) else max(1, (5 * pipe.group + 7) // 8)
-        self.order = pipe._since_idle                 # position in the current burst (0 = first group after an idle pipeline)
-        pipe._since_idle += 1
-        # a buffer of its own (the rows handed out to the caller stay valid as long as the caller keeps them); the caching
-        # allocator is told about every stream that touches it (record_stream)
-        self.llr = torch.empty((self.capacity * B, 1024), dtype=torch.float32, device=device)
+        self.capacity = pipe.group
+        self.device = device
+        # a buffer of its own (the rows handed out to the caller stay valid as long as the caller keeps them), allocated by the first
+        # submit on that batch's lane stream (`allocate`); the caching allocator is told about every other stream that touches it
+        self.llr = self.alloc_stream = self.alloc_ev = None
         self.throttle = prev.done if prev is not None else None
         self.lanes_used: set = set()
         self.ready: list = []
         self.count = 0
         self.scl = self.selected = self.done = None
+
+    def allocate(self, stream) -> None:
+        with torch.cuda.stream(stream):
+            self.llr = torch.empty((self.capacity * self.B, 1024), dtype=torch.float32, device=self.device)
+            self.alloc_ev = torch.cuda.Event()
+            self.alloc_ev.record()
+        self.alloc_stream = stream
 
 
 class GroupTicket:
@@ -733,6 +787,8 @@ class GroupTicket:
         self.synchronize()
         lo, hi = self.slot * self.g.B, (self.slot + 1) * self.g.B
         s = self.g.scl
+        if not getattr(self.g, "checked", False):
+            s.check(); self.g.checked = True                  # (the launch is complete: one small reduction per group)
         res = SclResult(s.hard_info[lo:hi], s.hard_ok[lo:hi], s.cand_info[lo:hi], s.cand_metric[lo:hi], s.cand_ok[lo:hi], s.ncand[lo:hi])
         if self.g.selected is not None:
             res.selected = tuple(t[lo:hi] for t in self.g.selected)
@@ -754,6 +810,8 @@ def select_payload(scl: SclResult, row: int = 0, validator=None):
     if hard_ok and (validator is None or _valid(hard)):
         return hard, True
     n = int(scl.ncand[row].item())
+    if n < 0:
+        raise nat.NativeError("es_scl_batch: this record was not decoded (no free scratch-slab slot)")
     if n == 0:      # list loop skipped although the shortcut did not return: only when validator is set
         raise RuntimeError("list decode was skipped; call scl(..., skip_if_hard_ok=False) when using a validator")
     infos = scl.cand_info[row].cpu().numpy()

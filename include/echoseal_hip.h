@@ -177,7 +177,9 @@ int es_header_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const in
  *   hard_info_dev   [B][55], hard_ok_dev [B]
  *   cand_info_dev   [B][L][55] candidates in ascending path-metric (stable) order
  *   cand_metric_dev [B][L] float64, cand_ok_dev [B][L] CRC flags
- *   ncand_dev       [B] int32: L, or 0 when the list loop was skipped (the record's candidate rows then read as zeros) */
+ *   ncand_dev       [B] int32: L, or 0 when the list loop was skipped (the record's candidate rows then read as zeros), or -1: the
+ *                   kernel could not decode the record (its block found no free slot of the scratch slab -- not reachable while resident
+ *                   blocks <= slots; reported, never silent: es_select_batch turns it into ok = -2 and the host layer raises) */
 int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int list_size,
                  int skip_if_hard_ok, uint8_t* hard_info_dev, uint8_t* hard_ok_dev,
                  uint8_t* cand_info_dev, double* cand_metric_dev, uint8_t* cand_ok_dev,
@@ -258,7 +260,8 @@ int es_aead_seal_batch(es_ctx* ctx, const uint8_t* key32_host, const uint8_t* no
  * candidate; else the lowest-metric candidate (ok = 0).  key32_host == NULL means validator=None; otherwise the
  * validator is the one of es_aead_check_batch with ctr_dev [B].  payload_dev [B][55]; ok_dev [B] int8 (1, 0, or
  * -1 when ncand is 0 although the shortcut did not return: run es_scl_batch with skip_if_hard_ok = 0 when a
- * validator is used); which_dev [B] int32 (-1 = hard candidate, else list index).                              */
+ * validator is used; -2 when ncand is negative: es_scl_batch reported that it could not decode the record -- its payload row
+ * is zeroed); which_dev [B] int32 (-1 = hard candidate, else list index).                              */
 int es_select_batch(es_ctx* ctx, const uint8_t* key32_host, const uint32_t* ctr_dev, int64_t B, int L,
                     const uint8_t* hard_info_dev, const uint8_t* hard_ok_dev, const uint8_t* cand_info_dev,
                     const double* cand_metric_dev, const uint8_t* cand_ok_dev, const int32_t* ncand_dev,

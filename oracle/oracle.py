@@ -125,6 +125,8 @@ def decode_frame(frame_f32, ba, tpl, taps, pn_full_bits, L=8, start=0):
     corr = ncc(y, tpl)
     thr, _, _ = cfar_threshold(corr)
     peaks, tot, fb = pick_peaks(corr, thr)
+    if isinstance(start, str):                       # "peak": demodulate at the first detected peak (config-3 windows)
+        start = int(peaks[0]) if tot else 0
     l, best_s, s0, s1 = llr(y[start:start + 1215], pn_full_bits[191:1215], taps)
     info, ok, took = polar_decode(l.astype(np.float64), L)
     return dict(y=y, corr=corr, thr=thr, peaks=peaks, npeaks=tot, fallback=fb, llr=l, best_s=best_s,

@@ -32,9 +32,25 @@ def test_rank_refuses_world_size_mismatch():
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
 
 
+def test_failing_rank_tears_the_job_down_within_seconds():
+    """A rank that dies while its peers wait in the rendezvous / a collective must not wedge the job: the launcher polls ALL children,
+    stops the others on the first non-zero exit and returns non-zero (CPU, gloo: rank 0 blocks in init_process_group waiting for
+    rank 1, which exits through the injected failure)."""
+    import time
+    env = dict(_env(), ES_BENCH_FAIL_RANK="1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--legs", "none"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    dt = time.time() - t0
+    assert p.returncode != 0 and "rank 1 exited" in p.stderr and not p.stdout.strip(), (p.returncode, p.stderr[-800:])
+    assert dt < 90, dt                           # (two interpreter starts with `import torch`; the default rendezvous timeout is 30 min)
+
+
 @pytest.mark.gpu
 def test_two_rank_rehearsal_and_checksum_independent_of_world_size():
-    common = ["--steps", "4", "--warmup", "1", "--legs", "c4", "--c4-frames", "16384", "--c4-chunk", "4096", "--no-cpu-baseline"]
+    """The default N > 1 line (headline C3 + legs c2 and c4) at two ranks (gloo rehearsal, both ranks on the one GPU), sized down."""
+    common = ["--steps", "2", "--warmup", "1", "--windows", "8192", "--legs", "c2,c4", "--c2-steps", "40", "--c4-frames", "16384", "--c4-chunk", "4096",
+              "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, BENCH, "--gpus", "1"] + common, env=_env(), capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo"] + common, env=_env(), capture_output=True,
@@ -42,6 +58,9 @@ def test_two_rank_rehearsal_and_checksum_independent_of_world_size():
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads(one.stdout.strip().splitlines()[-1]); j2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["config"]["world_size"] == 2
+    assert j1["config"]["workload"].startswith("C3:") and j2["scaling"] == "weak"
+    assert j1["config"]["results_identical_to_a_sequential_pass"] and j2["config"]["results_identical_to_a_sequential_pass"]
+    assert j2["legs"]["c2"]["scaling"] == "weak" and j2["legs"]["c2"]["sync_offsets_ok"]
     assert j2["legs"]["c4"]["frames_per_rank"] == 8192 and j2["legs"]["c4"]["scaling"] == "strong"
     assert j1["legs"]["c4"]["checksum"] == j2["legs"]["c4"]["checksum"]
     assert j1["legs"]["c4"]["frames_with_sync_offset_0"] == j2["legs"]["c4"]["frames_with_sync_offset_0"] == 16384
