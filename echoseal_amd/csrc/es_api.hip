@@ -31,29 +31,16 @@ int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_
     es_ctx::slab_use& u = ctx->slab[domain];
     const bool same = shareable && u.shareable && u.shape == shape;
     if (!same) {
-        for (auto& e : u.users)
-            if (e.first != st) ES_HIP_CHECK(ctx, hipStreamWaitEvent(st, e.second, 0));
-        // the outstanding launches are now ordered before this one: only this stream's entry needs to stay
-        for (size_t k = 0; k < u.users.size();) {
-            if (u.users[k].first != st) { (void)hipEventDestroy(u.users[k].second); u.users.erase(u.users.begin() + (long)k); }
-            else ++k;
-        }
+        // another slot geometry (or a kernel that indexes the slab by block): the outstanding launches on OTHER streams must have
+        // drained first.  No shipped pipeline does this (one context per stream); it is a host-side wait, not a silent overlap.
+        for (hipStream_t other : u.streams)
+            if (other != st) ES_HIP_CHECK(ctx, hipStreamSynchronize(other));
+        u.streams.clear();
     }
     u.shape = shape; u.shareable = shareable;
-    return ES_OK;
-}
-
-int es_slab_leave(es_ctx* ctx, int domain, hipStream_t st)
-{
-    if (capturing(st)) return ES_OK;
-    es_ctx::slab_use& u = ctx->slab[domain];
-    hipEvent_t ev = nullptr;
-    for (auto& e : u.users) if (e.first == st) ev = e.second;
-    if (!ev) {
-        ES_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        u.users.emplace_back(st, ev);
-    }
-    ES_HIP_CHECK(ctx, hipEventRecord(ev, st));
+    bool known = false;
+    for (hipStream_t other : u.streams) known = known || (other == st);
+    if (!known) u.streams.push_back(st);
     return ES_OK;
 }
 
@@ -131,7 +118,6 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_wide_slot_bits) (void)hipFree(ctx->d_wide_slot_bits);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
     if (ctx->d_hdr_pn) (void)hipFree(ctx->d_hdr_pn);
-    for (auto& u : ctx->slab) for (auto& e : u.users) (void)hipEventDestroy(e.second);
     delete ctx;
 }
 

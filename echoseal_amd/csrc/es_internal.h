@@ -43,10 +43,10 @@ struct es_ctx {
     unsigned* d_wide_slot_bits = nullptr;                 /* its slab slot bitmap (128 words: up to 3 072 one-wave blocks) */
     uint8_t* d_sbox = nullptr;        /* AES S-box (es_schedule_batch) */
     uint8_t* d_hdr_pn = nullptr;      /* packed header PN (es_tx_frames_batch) */
-    /* Who is using a scratch slab (es_slab_enter / es_slab_leave).  Domain 0 = d_scl_scratch (es_scl.hip, es_scl_multi.hip),
+    /* Who is using a scratch slab (es_slab_enter).  Domain 0 = d_scl_scratch (es_scl.hip, es_scl_multi.hip),
        domain 1 = d_wide_scratch (es_scl_wide.hip).  `shape`: how the launch cuts the slab into slots; launches of one shareable shape on
        several streams share the slab through its slot bitmap, anything else is ordered behind the outstanding launches. */
-    struct slab_use { int shape = -1; bool shareable = false; std::vector<std::pair<hipStream_t, hipEvent_t>> users; };
+    struct slab_use { int shape = -1; bool shareable = false; std::vector<hipStream_t> streams; };   /* streams that have launched with `shape` */
     slab_use slab[2];
     bool pick_attr_set = false;       /* per-device kernel attributes already raised for this context's device */
     unsigned wide_attr_mask = 0;      /* bit per instantiation of the lane-per-path list decoder (its list capacity 1 .. 256) */
@@ -69,12 +69,11 @@ static inline int es_wide_lanes_max(const es_ctx*) { return 256; }   /* lanes of
 /* kernels exist for power-of-two list sizes; a context created for list_size_max serves every size up to the next one */
 static inline int es_list_cap(int lmax) { int c = 1; while (c < lmax) c <<= 1; return c; }
 
-/* Slab ownership (es_api.hip): call es_slab_enter before and es_slab_leave after a launch that uses a scratch slab.
+/* Slab ownership (es_api.hip): call es_slab_enter before a launch that uses a scratch slab.
  * Launches on ONE stream are ordered by the stream.  Launches of one shareable shape (the kernels that claim slots from the slab's
- * bitmap) on several streams run concurrently.  A launch of another shape -- or of a kernel that indexes the slab by block -- on
- * another stream first waits (hipStreamWaitEvent) for every outstanding launch of the domain.  No-ops inside a stream capture. */
+ * bitmap) on several streams run concurrently.  A launch of another shape -- or of a kernel that indexes the slab by block -- first
+ * waits on the host (hipStreamSynchronize) for the other streams that launched with the previous shape.  No-op inside a stream capture. */
 int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_t st);
-int es_slab_leave(es_ctx* ctx, int domain, hipStream_t st);
 
 /* launchers implemented in the kernel translation units */
 size_t es_scl_scratch_bytes(const es_ctx* ctx);

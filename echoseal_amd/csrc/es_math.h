@@ -189,6 +189,19 @@ ES_HD double es_log1p(double x)
     return dk * ES_LN2_HI - ((hfsq - (s * (hfsq + R) + (dk * ES_LN2_LO + c))) - f);
 }
 
+/* max of two numbers (never NaN here): one of the operands, bit for bit.  On the device a bare v_max_f64 -- the builtin would first
+ * "canonicalise" operands that come straight from memory (two more instructions) to quieten signalling NaNs that cannot occur. */
+ES_HD double es_max_num(double x, double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#else
+    return x > y ? x : y;
+#endif
+}
+
 /* IEEE-754 quotient n / d for operands in the benign range the straight-line softplus below passes (d in [1, 3],
  * n zero or of magnitude in [2^-120, 2]): on the device, the division sequence hipcc emits for `/` (v_rcp_f64, two Newton
  * steps, quotient, residual, one correction) WITHOUT its range guards -- v_div_scale (which scales only operands whose
@@ -231,8 +244,6 @@ ES_HD double es_softplus_neg_generic(double t, const uint64_t* tab) { return es_
 ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
 {
     /* ---- exp(t), main path of es_exp ---- */
-    const uint64_t xb = es_d2u(t);
-    const uint32_t abstop = (uint32_t)(xb >> 52) & 0x7ffu;
     double kd = ES_FMA(t, ES_EXP_INVLN2N, ES_EXP_SHIFT);
     const uint64_t ki = es_d2u(kd);
     kd = kd - ES_EXP_SHIFT;
@@ -249,30 +260,25 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double r4 = r2 * r2;
     const double tmp = ES_FMA(r4, p45, tq);
     const double scale = es_u2d(sbits);
-    const double y = ES_FMA(scale, tmp, scale);           /* in (0, 1) */
+    const double y = ES_FMA(scale, tmp, scale);           /* in (0, 1] */
 
     /* ---- log1p(y) ---- */
     const int32_t hy = es_hi32(y);
     const int tiny29 = hy < 0x3e200000;                   /* y < 2^-29  -> y - y*y/2 (which is y itself below 2^-54) */
     const int k0 = hy < 0x3FDA827A;                       /* y < sqrt(2)-1: k = 0, f = y */
     const double u = 1.0 + y;
-    const int32_t hu0 = es_hi32(u);
-    const int32_t kk = (hu0 >> 20) - 1023;
-    /* y <= 1 here, so u <= 2 and es_log1p's two forms of the rounding error of 1 + y coincide: for u < 2 (kk == 0) it
-       takes y - (u - 1); at u == 2 (y == 1, kk == 1) its 1 - (u - y) and this expression are both exactly 0 */
+    const uint32_t hu0 = (uint32_t)es_hi32(u);
+    /* y <= 1 here, so u <= 2 and es_log1p's two forms of the rounding error of 1 + y coincide: for u < 2 (exponent 0) it
+       takes y - (u - 1); at u == 2 (y == 1, exponent 1) its 1 - (u - y) and this expression are both exactly 0 */
     const double cn1 = y - (u - 1.0);
-    const int32_t hum = hu0 & 0x000fffff;
-    const int big = hum >= 0x6a09e;
-    const int32_t k1 = kk + (big ? 1 : 0);
-    const uint32_t newhi = (uint32_t)(hum | (big ? 0x3fe00000 : 0x3ff00000));
-    const double un = es_u2d((es_d2u(u) & 0xffffffffULL) | ((uint64_t)newhi << 32));
-    const int32_t hu1 = big ? ((0x00100000 - hum) >> 2) : hum;
-    const double f = k0 ? y : un - 1.0;
-    const int32_t k = k0 ? 0 : k1;
-    const int32_t hu = k0 ? 1 : hu1;
+    /* k != 0.  Then k == 1: y >= sqrt(2)-1 puts 1 + y in [1.41421353.., 2], whose high word is >= 0x3ff6a09e (fdlibm: k = 0 + 1) or, at
+       u == 2, has a zero fraction (k = 1 + 0).  fdlibm rewrites u's exponent so that u/2 remains (1.0 when u == 2) and takes
+       f = that - 1: halving is exact, so ONE fma(u, 0.5, -1) rounds exactly as that subtraction does.  With k == 1 the products
+       k*ln2_hi and k*ln2_lo are the constants themselves. */
+    const double f1 = ES_FMA(u, 0.5, -1.0);
+    const double f = k0 ? y : f1;
     const double c = es_div_normal(cn1, u);               /* only read when k != 0, where es_log1p divides exactly these */
     const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
     const double s = es_div_normal(f, 2.0 + f);
     const double z = s * s;
     const double R1 = z * ES_LP1;
@@ -285,15 +291,16 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double R = ((R1 + z2 * R2) + z4 * R3) + z6 * R4;
     const double sR = s * (hfsq + R);
     const double res0 = f - (hfsq - sR);
-    const double resk = dk * ES_LN2_HI - ((hfsq - (sR + (dk * ES_LN2_LO + c))) - f);
-    double res = (k == 0) ? res0 : resk;
+    const double resk = ES_LN2_HI - ((hfsq - (sR + (ES_LN2_LO + c))) - f);
+    double res = k0 ? res0 : resk;
     const double rt = y - y * y * 0.5;
     res = tiny29 ? rt : res;
     /* Range of the straight-line form.  exp: every |t| < 512 -- below 2^-54 (in practice t == 0, which two LLRs clipped
      * to the same +-12 produce all the time) the main path yields exactly the 1.0 that es_exp's early return (1 + t)
-     * rounds to.  log1p: its |f| < 2^-20 corner (hu == 0) is left to the generic form, EXCEPT f == 0 (y == 1, i.e.
-     * that t == 0 case), where fdlibm's shortcut  k*ln2_hi + (c + k*ln2_lo)  is what resk evaluates to term by term. */
-    *ok = (abstop < 0x3c9u + 0x3fu) && (tiny29 || hu != 0 || f == 0.0);
+     * rounds to.  log1p: its |f| < 2^-20 corner (fdlibm's hu == 0: for k == 1 the fraction field of u's high word is >= 0xffffd,
+     * i.e. the high word is 0x3ffffffd..0x3fffffff) is left to the generic form; at u == 2 (y == 1, that t == 0 case; high word
+     * 0x40000000) f == 0 and fdlibm's shortcut  k*ln2_hi + (c + k*ln2_lo)  is what resk evaluates to term by term. */
+    *ok = (__builtin_fabs(t) < 512.0) && ((uint32_t)(hu0 - 0x3FFFFFFDu) >= 3u);
     return res;
 }
 
@@ -332,14 +339,14 @@ ES_HD double es_logaddexp(double x, double y, const uint64_t* tab)
  * which are exactly the penalties log1p(exp(-|g|)) of the sibling leaf g = b -/+ a. */
 ES_HD double es_polar_f_sp(double a, double b, const uint64_t* tab, double* sp_diff, double* sp_sum)
 {
-    /* two independent softplus evaluations, written out so that they can be interleaved */
+    /* npy_logaddexp(x, y) is  max(x, y) + log1p(exp(-|x - y|))  -- its branch on the sign of x - y picks exactly that -- and
+       x + ln 2 when x == y, which the formula gives too: log1p(exp(-0)) evaluates to ln2_hi + ln2_lo = the double nearest ln 2 =
+       npymath's LOGE2 (tests/test_oracle_math.py pins f against NumPy on equal and opposite operands).  Two independent softplus
+       evaluations, written out so that they can be interleaved. */
     const double d1 = a - b;
-    const int pos1 = d1 > 0;
     const double sum = a + b;
-    const double d2 = 0.0 - sum;
-    const int pos2 = d2 > 0;
-    const double t1 = pos1 ? -d1 : d1;
-    const double t2 = pos2 ? -d2 : d2;
+    const double t1 = -__builtin_fabs(d1);
+    const double t2 = -__builtin_fabs(sum);
     int ok1, ok2;
     double L1 = es_softplus_neg_fast(t1, tab, &ok1);
     double L2 = es_softplus_neg_fast(t2, tab, &ok2);
@@ -347,10 +354,8 @@ ES_HD double es_polar_f_sp(double a, double b, const uint64_t* tab, double* sp_d
     if (!ok2) L2 = es_softplus_neg_generic(t2, tab);
     *sp_diff = L1;
     *sp_sum = L2;
-    double r1 = (pos1 ? a : b) + L1;                     /* logaddexp(a, b)     */
-    if (a == b) r1 = a + ES_LOGE2;
-    double r2 = (pos2 ? 0.0 : sum) + L2;                 /* logaddexp(0, a + b) */
-    if (0.0 == sum) r2 = 0.0 + ES_LOGE2;
+    const double r1 = es_max_num(a, b) + L1;             /* logaddexp(a, b)     */
+    const double r2 = es_max_num(sum, 0.0) + L2;         /* logaddexp(0, a + b) */
     return r1 - r2;
 }
 

@@ -40,8 +40,9 @@
 #ifndef ES_WIDE_GBATCH
 #define ES_WIDE_GBATCH 8                          /* load pairs in flight in the lane-serial g loops (divides 8; 8: +1 % over 4, measured) */
 #endif
-#ifndef ES_WIDE_PREFETCH
-#define ES_WIDE_PREFETCH 2                        /* parent pairs loaded ahead in the lane-serial f loops (2: +2.4 % over 1 at L = 8, measured) */
+
+#ifndef ES_WIDE_FDIST
+#define ES_WIDE_FDIST 2                           /* f loops: operand pairs requested this many f evaluations ahead (1: rotation by copy; 2: unrolled by three) */
 #endif
 
 namespace {
@@ -434,43 +435,59 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                     const int ps = (d > 1) ? p8_get(pa_, d - 2) : 0;
                     const double* par = A + (long long)(2 * S) * L + ps;          // depth d-1 block at elements [2S, 4S)
                     double* dst = A + (long long)S * L + p;                        // depth d block at elements [S, 2S)
-                    auto ld_pair = [&](int j, double& pa, double& pb) {
-                        if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
-                        else { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; }
-                    };
+                    // The loaders are chosen OUTSIDE the element loops (slab / float32 LLRs / float64 LLRs): a branch inside a loader puts
+                    // control flow between a load and its use, and the compiler then waits for ALL outstanding loads (s_waitcnt vmcnt(0)) right
+                    // after issuing each pair -- the batches below would run one memory round trip per pair instead of GBATCH pairs in flight.
+                    auto ld_slab = [&](int j, double& pa, double& pb) { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; };
                     if (is_g) {
                         const int bs = (d <= 5) ? p8_get(pb_, d - 1) : 0;
-                        for (int j0 = 0; j0 < S; j0 += 32) {
-                            uint32_t wbits; int nb;
-                            if (S >= 32) { wbits = beta_ld((S + j0) >> 5, bs); nb = 32; }
-                            else { wbits = b0 >> S; nb = S; }
-                            for (int u = 0; u < nb; u += ES_WIDE_GBATCH) {         // (g is an add: the loop is memory latency) GBATCH independent load pairs in flight
-                                double xa[ES_WIDE_GBATCH], xb[ES_WIDE_GBATCH];
-                                #pragma unroll
-                                for (int v = 0; v < ES_WIDE_GBATCH; ++v) ld_pair(j0 + u + v, xa[v], xb[v]);
-                                #pragma unroll
-                                for (int v = 0; v < ES_WIDE_GBATCH; ++v) dst[(long long)(j0 + u + v) * L] = es_polar_g(xa[v], xb[v], (wbits >> (u + v)) & 1u);
+                        auto g_level = [&](auto ld) {
+                            for (int j0 = 0; j0 < S; j0 += 32) {
+                                uint32_t wbits; int nb;
+                                if (S >= 32) { wbits = beta_ld((S + j0) >> 5, bs); nb = 32; }
+                                else { wbits = b0 >> S; nb = S; }
+                                for (int u = 0; u < nb; u += ES_WIDE_GBATCH) {     // (g is an add: the loop is memory latency) GBATCH independent load pairs in flight
+                                    double xa[ES_WIDE_GBATCH], xb[ES_WIDE_GBATCH];
+                                    #pragma unroll
+                                    for (int v = 0; v < ES_WIDE_GBATCH; ++v) ld(j0 + u + v, xa[v], xb[v]);
+                                    #pragma unroll
+                                    for (int v = 0; v < ES_WIDE_GBATCH; ++v) dst[(long long)(j0 + u + v) * L] = es_polar_g(xa[v], xb[v], (wbits >> (u + v)) & 1u);
+                                }
                             }
-                        }
+                        };
+                        if (d > 1) g_level(ld_slab);
+                        else if (a.is_f64) g_level([&](int j, double& pa, double& pb) { pa = llr64[j]; pb = llr64[j + S]; });      // d == 1 (i == 512): the channel LLRs
+                        else g_level([&](int j, double& pa, double& pb) { pa = (double)llr32[j]; pb = (double)llr32[j + S]; });
                     } else {
-#if ES_WIDE_PREFETCH == 2
+                        // an f level is never the top of a step (the top is the g whose bit was just decided): d >= 2, operands from the slab
+#if ES_WIDE_FDIST == 2
+                        // three operand pairs in rotation, the loop unrolled by three so that the rotation is a renaming, not a copy (a copy of a
+                        // register that a load is still filling waits for the load): the operands of element j + 3 are requested right after
+                        // f(j) and used two f evaluations later.  Loads past the end re-read the last element (S >= 8).
+                        double a0, b0_, a1, b1_, a2, b2_;
+                        ld_slab(0, a0, b0_); ld_slab(1, a1, b1_); ld_slab(2, a2, b2_);
+                        for (int j = 0; ; j += 3) {
+                            dst[(long long)j * L] = es_polar_f(a0, b0_, tab);
+                            if (j + 1 >= S) break;
+                            ld_slab(j + 3 < S ? j + 3 : S - 1, a0, b0_);
+                            dst[(long long)(j + 1) * L] = es_polar_f(a1, b1_, tab);
+                            if (j + 2 >= S) break;
+                            ld_slab(j + 4 < S ? j + 4 : S - 1, a1, b1_);
+                            dst[(long long)(j + 2) * L] = es_polar_f(a2, b2_, tab);
+                            if (j + 3 >= S) break;
+                            ld_slab(j + 5 < S ? j + 5 : S - 1, a2, b2_);
+                        }
+#else
                         double pa, pb, qa, qb;                                   // operands of elements j+1 and j+2 are on their way while f(j) runs (S >= 8)
-                        ld_pair(0, pa, pb); ld_pair(1, qa, qb);
-                        for (int j = 0; j < S; ++j) {
-                            double na = 0.0, nb = 0.0;
-                            if (j + 2 < S) ld_pair(j + 2, na, nb);
+                        ld_slab(0, pa, pb); ld_slab(1, qa, qb);
+                        for (int j = 0; j < S - 2; ++j) {
+                            double na, nb;
+                            ld_slab(j + 2, na, nb);
                             dst[(long long)j * L] = es_polar_f(pa, pb, tab);
                             pa = qa; pb = qb; qa = na; qb = nb;
                         }
-#else
-                        double pa, pb;                                           // operands of element j+1 are loaded while f(j) runs
-                        ld_pair(0, pa, pb);
-                        for (int j = 0; j < S; ++j) {
-                            double na = 0.0, nb = 0.0;
-                            if (j + 1 < S) ld_pair(j + 1, na, nb);
-                            dst[(long long)j * L] = es_polar_f(pa, pb, tab);
-                            pa = na; pb = nb;
-                        }
+                        dst[(long long)(S - 2) * L] = es_polar_f(pa, pb, tab);
+                        dst[(long long)(S - 1) * L] = es_polar_f(qa, qb, tab);
 #endif
                     }
                     pa_ = p8_set(pa_, d - 1, p);
@@ -668,7 +685,7 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
     { const int rc = es_slab_enter(ctx, 1, 0x300 | L, true, st); if (rc) return rc; }       // slot stride depends on the block's lanes only
     hipLaunchKernelGGL((es_scl_wide_kernel<L, LF>), dim3((unsigned)blocks), dim3(L), lds, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
-    return es_slab_leave(ctx, 1, st);
+    return ES_OK;
 }
 
 }  // namespace

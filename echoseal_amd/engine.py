@@ -15,8 +15,8 @@ sync + LLR (variant 0, known start/counter) + SCL-L.
 from __future__ import annotations
 
 import os
+import sys
 import warnings
-import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -33,7 +33,8 @@ HW_QUEUES_WANTED = 8
 if "GPU_MAX_HW_QUEUES" not in os.environ and not torch.cuda.is_initialized():
     os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES_WANTED)
 _HWQ_ENV_AT_IMPORT = os.environ.get("GPU_MAX_HW_QUEUES")      # None: HIP was already up, without the variable
-_LIVE_STREAMS: "weakref.WeakSet" = weakref.WeakSet()           # streams made by DecodePipeline objects that are still alive
+_LIVE_STREAMS = [0]                                            # streams made through pipeline_streams and not yet given back (a plain count:
+                                                               # weak references to torch.cuda.Stream objects crash the interpreter's final GC)
 
 
 def hw_queue_budget() -> int:
@@ -49,10 +50,12 @@ def pipeline_streams(device, n: int, priority: int = 0) -> list:
     """n new HIP streams, counted against the hardware-queue budget (DecodePipeline makes its own through this; a process that builds
     several pipelines makes the streams once and hands them to each: DecodePipeline(streams=...))."""
     out = [torch.cuda.Stream(device, priority=priority) for _ in range(n)]
-    for st in out:
-        _LIVE_STREAMS.add(st)
-    if len(_LIVE_STREAMS) > hw_queue_budget():
-        warnings.warn(f"DecodePipeline: {len(_LIVE_STREAMS)} pipeline streams are alive but the HIP runtime has {hw_queue_budget()} hardware queues "
+    _LIVE_STREAMS[0] += n
+    if _LIVE_STREAMS[0] > hw_queue_budget():
+        import gc
+        gc.collect()                                # (pipelines that are garbage but not yet collected still count their streams)
+    if _LIVE_STREAMS[0] > hw_queue_budget():
+        warnings.warn(f"DecodePipeline: {_LIVE_STREAMS[0]} pipeline streams are alive but the HIP runtime has {hw_queue_budget()} hardware queues "
                       f"(GPU_MAX_HW_QUEUES{'=' + _HWQ_ENV_AT_IMPORT if _HWQ_ENV_AT_IMPORT else ' was not set before HIP initialised'}): streams that share a "
                       "queue serialise.  Set GPU_MAX_HW_QUEUES=8 before the first GPU call (importing echoseal_amd.engine first does it), "
                       "and hand existing streams to further pipelines (streams=...).", RuntimeWarning, stacklevel=3)
@@ -123,7 +126,8 @@ class RxEngine:
 
     def __del__(self):  # pragma: no cover
         try:
-            self.close()
+            if not sys.is_finalizing():            # at interpreter shutdown the HIP runtime may already be gone; the OS reclaims the rest
+                self.close()
         except Exception:
             pass
 
@@ -537,6 +541,20 @@ class DecodePipeline:
         self.eng = eng
         self.list_size = int(list_size)
         dev = eng.device
+        self._own_streams = 0                         # streams this pipeline made itself (given back to the budget when it is collected)
+        self._build(eng, dev, scl_streams, depth, lanes, side_stream, group, streams)
+
+    def _mk(self, device, n: int, priority: int = 0) -> list:
+        self._own_streams += n
+        return pipeline_streams(device, n, priority)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            _LIVE_STREAMS[0] -= self._own_streams
+        except Exception:
+            pass
+
+    def _build(self, eng, dev, scl_streams, depth, lanes, side_stream, group, streams) -> None:
         # `group` > 0: the throughput arrangement -- the front ends (band-pass .. demodulator) of `group` consecutive batches
         # run on `lanes` front streams and write their LLR rows into ONE buffer, and ONE list-decoder launch (on one of
         # `scl_streams` streams, own context, one lane per path: es_set_option "scl_lanes" = 1) decodes the whole group:
@@ -549,11 +567,11 @@ class DecodePipeline:
             nb = max(1, int(scl_streams))
             # the short front-end kernels get dispatch priority: they must slip in whenever list-decoder waves leave
             # `streams` = (front-end streams, list-decoder streams) to run on instead of new ones
-            self.lane_streams = list(streams[0])[:self.lanes] if streams is not None else pipeline_streams(dev, self.lanes, priority=-1)
+            self.lane_streams = list(streams[0])[:self.lanes] if streams is not None else self._mk(dev, self.lanes, priority=-1)
             if len(self.lane_streams) != self.lanes:
                 raise ValueError("streams: one front-end stream per lane")
             self.lane_engs = [eng] + [RxEngine(dev, list_size_max=0) for _ in range(self.lanes - 1)]     # front-end contexts: no list-decoder scratch
-            self.backs = list(streams[1])[:nb] if streams is not None else pipeline_streams(dev, nb)
+            self.backs = list(streams[1])[:nb] if streams is not None else self._mk(dev, nb)
             if len(self.backs) != nb:
                 raise ValueError("streams: one list-decoder stream per scl_streams")
             self.scl_engs = [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in range(nb)]
@@ -572,7 +590,7 @@ class DecodePipeline:
             # (lane 0 on the caller's own stream was measured slower: 1.29 M against 1.43 M frames/s at 7 lanes)
             # `streams`: HIP streams to run the lanes on instead of new ones -- a process that builds several pipelines should hand
             # the same streams to each: beyond GPU_MAX_HW_QUEUES (8) live streams, streams share hardware queues and serialise
-            self.lane_streams = list(streams)[:self.lanes] if streams is not None else pipeline_streams(dev, self.lanes)
+            self.lane_streams = list(streams)[:self.lanes] if streams is not None else self._mk(dev, self.lanes)
             if len(self.lane_streams) != self.lanes:
                 raise ValueError("streams: one per lane")
             self.lane_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in range(self.lanes - 1)]
@@ -582,9 +600,9 @@ class DecodePipeline:
             self._k = 0
             return
         # the short front-end kernels get dispatch priority over the long-running list decoders
-        self.front = pipeline_streams(dev, 1, priority=-1)[0]
-        self.side = pipeline_streams(dev, 1, priority=-1)[0] if side_stream else self.front   # one hardware queue less without it
-        self.backs = pipeline_streams(dev, max(1, int(scl_streams)))
+        self.front = self._mk(dev, 1, priority=-1)[0]
+        self.side = self._mk(dev, 1, priority=-1)[0] if side_stream else self.front   # one hardware queue less without it
+        self.backs = self._mk(dev, max(1, int(scl_streams)))
         self.scl_engs = [eng] + [RxEngine(dev, list_size_max=max(8, self.list_size)) for _ in self.backs[1:]]
         # Batches in flight = list-decoder streams: the front end of batch k waits for batch k-2 to leave, so it
         # runs while only ONE list decoder is resident (two of them fill every SIMD's register file and would

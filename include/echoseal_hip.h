@@ -135,8 +135,8 @@ int es_front_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, in
  * list_size_max <= 32 by es_set_option "scl_lane_slab" / "scl_lanes" = 1 -- set those before the first enqueue-only call as well.
  * Streams: the float64 workspace is shared by every call on the context (one stream at a time for the entry points that use it).  The list
  * decoder's slabs are guarded: es_scl_batch launches on one stream are ordered by the stream, launches of the same slot geometry on several
- * streams share the slab through its slot bitmap, and a launch of another geometry on another stream is made to wait (hipStreamWaitEvent)
- * for the outstanding ones.                                                                                                          */
+ * streams share the slab through its slot bitmap, and a launch of another geometry on another stream first waits on the host
+ * (hipStreamSynchronize) for the streams that used the previous one.                                                                                                         */
 int es_reserve(es_ctx* ctx, int64_t B_max, int T_max);
 
 /* Convenience: the three float64 calls above back to back (workspace owned by the context). */
