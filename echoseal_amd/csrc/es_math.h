@@ -360,6 +360,30 @@ ES_HD double es_polar_f_sp(double a, double b, const uint64_t* tab, double* sp_d
 }
 
 
+/* The same value WITHOUT the generic fall-back: straight-line code only.  Lanes whose operands leave the range of the straight-line
+ * softplus set *bad (or-ed in) and get an unspecified result; the caller recomputes those with es_polar_f_sp (a cold path OUTSIDE its hot
+ * loop: a call inside a loop makes the compiler wait for every outstanding load at the loop head and keeps the two chains apart). */
+ES_HD double es_polar_f_fast_sp(double a, double b, const uint64_t* tab, double* sp_diff, double* sp_sum, int* bad)
+{
+    const double d1 = a - b;
+    const double sum = a + b;
+    int ok1, ok2;
+    const double L1 = es_softplus_neg_fast(-__builtin_fabs(d1), tab, &ok1);
+    const double L2 = es_softplus_neg_fast(-__builtin_fabs(sum), tab, &ok2);
+    *bad |= !(ok1 & ok2);
+    *sp_diff = L1;
+    *sp_sum = L2;
+    const double r1 = es_max_num(a, b) + L1;
+    const double r2 = es_max_num(sum, 0.0) + L2;
+    return r1 - r2;
+}
+
+ES_HD double es_polar_f_fast(double a, double b, const uint64_t* tab, int* bad)
+{
+    double s0, s1;
+    return es_polar_f_fast_sp(a, b, tab, &s0, &s1, bad);
+}
+
 ES_HD double es_polar_f(double a, double b, const uint64_t* tab)
 {
     double s0, s1;

@@ -41,6 +41,12 @@
 #define ES_WIDE_GBATCH 8                          /* load pairs in flight in the lane-serial g loops (divides 8; 8: +1 % over 4, measured) */
 #endif
 
+#ifndef ES_WIDE_FUSE_GF
+#define ES_WIDE_FUSE_GF 1                         /* 1: the g at the top of a step and the f level below it in one pass (slab levels 2..6); 3: also pairs of f levels */
+#endif
+#ifndef ES_WIDE_DEFER
+#define ES_WIDE_DEFER 12                          /* where the generic softplus is a deferred cold path instead of a branch after each evaluation: 1 slab f loops, 2 depth 8, 4 depth 9, 8 depth 10 */
+#endif
 #ifndef ES_WIDE_FDIST
 #define ES_WIDE_FDIST 2                           /* f loops: operand pairs requested this many f evaluations ahead (1: rotation by copy; 2: unrolled by three) */
 #endif
@@ -249,6 +255,12 @@ __device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, 
 #endif
 }
 
+// cold path of the slab f loops: the whole level again with the generic softplus where a lane needs it (values identical for the others)
+__device__ __attribute__((noinline)) void f_level_exact(const double* par, double* dst, int S, int L, const uint64_t* tab)
+{
+    for (int j = 0; j < S; ++j) dst[(long long)j * L] = es_polar_f(par[(long long)j * L], par[(long long)(j + S) * L], tab);
+}
+
 // hard decision -> butterfly -> data bits -> CRC of one frame by one wave (fastpolar.py:260-268); returns the CRC verdict to every lane
 __device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long ff, int lane, uint32_t* hardw, uint8_t* hbytes, const uint16_t* dpos)
 {
@@ -439,6 +451,64 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                     // control flow between a load and its use, and the compiler then waits for ALL outstanding loads (s_waitcnt vmcnt(0)) right
                     // after issuing each pair -- the batches below would run one memory round trip per pair instead of GBATCH pairs in flight.
                     auto ld_slab = [&](int j, double& pa, double& pb) { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; };
+#if ES_WIDE_FUSE_GF
+                    if (d > 1 && d < 7 && (is_g || (ES_WIDE_FUSE_GF & 2))) {
+                        // Two levels in ONE pass: level d (the g of the bit just decided when it is the top of the step, else an f) and the f
+                        // level below it.  The two level-d results that make an f operand pair -- elements i and i + S/2 -- are formed
+                        // together, stored (their g child reads them later) and consumed from registers, so that level d+1 does not read
+                        // back what was written S elements earlier (at these sizes from the Infinity Cache or HBM).
+                        const int bs = (is_g && d <= 5) ? p8_get(pb_, d - 1) : 0;
+                        const int H = S >> 1;
+                        double* dstB = A + (long long)H * L + p;                   // depth d+1 block at elements [H, 2H)
+                        auto ld4 = [&](int j, double (&q)[4]) {
+                            q[0] = par[(long long)j * L]; q[1] = par[(long long)(j + S) * L];
+                            q[2] = par[(long long)(j + H) * L]; q[3] = par[(long long)(j + H + S) * L];
+                        };
+                        auto pair_gf = [&](int j, const double (&q)[4], uint32_t u1, uint32_t u2) {
+                            const double g1 = es_polar_g(q[0], q[1], u1), g2 = es_polar_g(q[2], q[3], u2);
+                            dst[(long long)j * L] = g1;
+                            dst[(long long)(j + H) * L] = g2;
+                            dstB[(long long)j * L] = es_polar_f(g1, g2, tab);
+                        };
+                        auto pair_ff = [&](int j, const double (&q)[4]) {
+                            const double f1 = es_polar_f(q[0], q[1], tab);
+                            dst[(long long)j * L] = f1;
+                            const double f2 = es_polar_f(q[2], q[3], tab);
+                            dst[(long long)(j + H) * L] = f2;
+                            dstB[(long long)j * L] = es_polar_f(f1, f2, tab);
+                        };
+                        const int blk = H < 32 ? H : 32;
+                        for (int i0 = 0; i0 < H; i0 += blk) {
+                            uint32_t w1 = 0, w2 = 0;                                // partial-sum bits of elements i0 .. and i0 + H ..
+                            if (is_g) {
+                                if (S >= 64) { w1 = beta_ld((S + i0) >> 5, bs); w2 = beta_ld((S + i0 + H) >> 5, bs); }
+                                else if (S == 32) { w1 = beta_ld(1, bs); w2 = w1 >> 16; }
+                                else { w1 = b0 >> S; w2 = w1 >> H; }
+                            }
+                            double q0[4], q1[4];
+                            ld4(i0, q0); ld4(i0 + 1, q1);
+                            if (is_g) {
+                                for (int u = 0; u < blk; u += 2) {                  // two operand sets in rotation (renamed, not copied)
+                                    pair_gf(i0 + u, q0, (w1 >> u) & 1u, (w2 >> u) & 1u);
+                                    ld4(u + 2 < blk ? i0 + u + 2 : i0 + blk - 1, q0);
+                                    pair_gf(i0 + u + 1, q1, (w1 >> (u + 1)) & 1u, (w2 >> (u + 1)) & 1u);
+                                    ld4(u + 3 < blk ? i0 + u + 3 : i0 + blk - 1, q1);
+                                }
+                            } else {
+                                for (int u = 0; u < blk; u += 2) {
+                                    pair_ff(i0 + u, q0);
+                                    ld4(u + 2 < blk ? i0 + u + 2 : i0 + blk - 1, q0);
+                                    pair_ff(i0 + u + 1, q1);
+                                    ld4(u + 3 < blk ? i0 + u + 3 : i0 + blk - 1, q1);
+                                }
+                            }
+                        }
+                        pa_ = p8_set(pa_, d - 1, p);
+                        ++d;                                                        // level d+1 is done too
+                        pa_ = p8_set(pa_, d - 1, p);
+                        continue;
+                    }
+#endif
                     if (is_g) {
                         const int bs = (d <= 5) ? p8_get(pb_, d - 1) : 0;
                         auto g_level = [&](auto ld) {
@@ -464,6 +534,25 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                         // three operand pairs in rotation, the loop unrolled by three so that the rotation is a renaming, not a copy (a copy of a
                         // register that a load is still filling waits for the load): the operands of element j + 3 are requested right after
                         // f(j) and used two f evaluations later.  Loads past the end re-read the last element (S >= 8).
+                        // The loop body is straight-line: operands outside the range of the straight-line softplus (|t| >= 512, or 1 + e^t within
+                        // 3 * 2^-20 below 2) only raise `bad`, and the level is then redone with the generic form in a cold loop after it.
+#if ES_WIDE_DEFER & 1
+                        double a0, b0_, a1, b1_, a2, b2_;
+                        int bad = 0;
+                        ld_slab(0, a0, b0_); ld_slab(1, a1, b1_); ld_slab(2, a2, b2_);
+                        for (int j = 0; ; j += 3) {
+                            dst[(long long)j * L] = es_polar_f_fast(a0, b0_, tab, &bad);
+                            if (j + 1 >= S) break;
+                            ld_slab(j + 3 < S ? j + 3 : S - 1, a0, b0_);
+                            dst[(long long)(j + 1) * L] = es_polar_f_fast(a1, b1_, tab, &bad);
+                            if (j + 2 >= S) break;
+                            ld_slab(j + 4 < S ? j + 4 : S - 1, a1, b1_);
+                            dst[(long long)(j + 2) * L] = es_polar_f_fast(a2, b2_, tab, &bad);
+                            if (j + 3 >= S) break;
+                            ld_slab(j + 5 < S ? j + 5 : S - 1, a2, b2_);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ULL) f_level_exact(par, dst, S, L, tab);     // rare
+#else
                         double a0, b0_, a1, b1_, a2, b2_;
                         ld_slab(0, a0, b0_); ld_slab(1, a1, b1_); ld_slab(2, a2, b2_);
                         for (int j = 0; ; j += 3) {
@@ -477,6 +566,7 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                             if (j + 3 >= S) break;
                             ld_slab(j + 5 < S ? j + 5 : S - 1, a2, b2_);
                         }
+#endif
 #else
                         double pa, pb, qa, qb;                                   // operands of elements j+1 and j+2 are on their way while f(j) runs (S >= 8)
                         ld_slab(0, pa, pb); ld_slab(1, qa, qb);
@@ -502,8 +592,21 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                         #pragma unroll
                         for (int j = 0; j < 4; ++j) W.low[j][p] = es_polar_g(x[j], x[j + 4], (b0 >> (4 + j)) & 1u);
                     } else {
+#if ES_WIDE_DEFER & 2
+                        int bad = 0;
+                        double y8[4];
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j) y8[j] = es_polar_f_fast(x[j], x[j + 4], tab, &bad);
+                        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ULL) {          // rare: the generic form
+                            #pragma unroll 1
+                            for (int j = 0; j < 4; ++j) y8[j] = es_polar_f(x[j], x[j + 4], tab);
+                        }
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j) W.low[j][p] = y8[j];
+#else
                         #pragma unroll 2
                         for (int j = 0; j < 4; ++j) W.low[j][p] = es_polar_f(x[j], x[j + 4], tab);
+#endif
                     }
                     pa_ = p8_set(pa_, 7, p);
                 }
@@ -515,8 +618,16 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                         W.low[4][p] = es_polar_g(x0, x2, (b0 >> 2) & 1u);
                         W.low[5][p] = es_polar_g(x1, x3, (b0 >> 3) & 1u);
                     } else {
+#if ES_WIDE_DEFER & 4
+                        int bad = 0;
+                        double y0 = es_polar_f_fast(x0, x2, tab, &bad), y1 = es_polar_f_fast(x1, x3, tab, &bad);
+                        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ULL) { y0 = es_polar_f(x0, x2, tab); y1 = es_polar_f(x1, x3, tab); }
+                        W.low[4][p] = y0;
+                        W.low[5][p] = y1;
+#else
                         W.low[4][p] = es_polar_f(x0, x2, tab);
                         W.low[5][p] = es_polar_f(x1, x3, tab);
+#endif
                     }
                     pb_ = p8_set(pb_, 5, p);
                 }
@@ -525,7 +636,15 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
                     const int ps = p8_get(pb_, 5);
                     const double xa = W.low[4][ps], xb = W.low[5][ps];
                     if (i & 1) lam = es_polar_g(xa, xb, (b0 >> 1) & 1u);
+#if ES_WIDE_DEFER & 8
+                    else {
+                        int bad = 0;
+                        lam = es_polar_f_fast_sp(xa, xb, tab, &sp_diff, &sp_sum, &bad);
+                        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ULL) lam = es_polar_f_sp(xa, xb, tab, &sp_diff, &sp_sum);
+                    }
+#else
                     else lam = es_polar_f_sp(xa, xb, tab, &sp_diff, &sp_sum);
+#endif
                 }
                 dirty = true;
             }

@@ -195,6 +195,117 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void es_bpf_quad_kernel(const void* 
     }
 }
 
+// ---------------------------------------------------------------------------------------- BPF (row)
+// Few, long records (verify() on a recording: four bands x 240 000 samples): the recursion of ONE record is the whole run time, and a
+// wave on its own issues one vector instruction per ~5.5 cycles whatever it is -- so what counts is the number of instructions per
+// sample.  Here a record owns a DPP row of 16 lanes, lanes 0..7 of which hold one delay element each (z[k] in lane k; lanes 8..15 are
+// switched off during the recursion and only help with staging): per sample every lane forms b[k+1] x, b[0] x and z + b[0] x (lane 0's
+// is y), y reaches the row with ONE v_mov_b64_dpp row_newbcast:0, z[k+1] comes from the right-hand neighbour with a row_shl:1 move
+// per half, then (z[k+1] + b[k+1] x) - a[k+1] y: nine vector instructions per sample against seventeen with four lanes per record.
+// Lane 7 has no upper neighbour: its source lane 8 is disabled, so the move leaves lane 7's register at the -0.0 it was given at the
+// start and -0.0 + t == t for every t, signed zeros included (an exact "no neighbour").  Arithmetic and its order are SciPy's
+// direct-form-II-transposed loop (separate multiply and add), as in the other two kernels; bit-exactness is pinned by the same tests.
+#ifndef ES_BPF_ROW_FMAC
+#define ES_BPF_ROW_FMAC 0                          /* 1: a[k+1] y through v_fmac_f64_dpp (same bits, same speed: measured) */
+#endif
+constexpr int BR_TT = 32;                           // samples per tile
+constexpr int BR_RECS = 4;                          // records per wave (one per DPP row)
+
+template <bool I16>
+__global__ __launch_bounds__(64) void es_bpf_row_kernel(const void* __restrict__ frames,
+        long long B, int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
+        double* __restrict__ y, float* __restrict__ y32)
+{
+    __shared__ double s_x[BR_RECS][BR_TT];
+    __shared__ double s_y[BR_RECS][BR_TT];
+    const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    const long long rec0 = (long long)blockIdx.x * BR_RECS;
+    const int row = lane >> 4, k = lane & 15;
+    const long long rec = rec0 + row;
+    const bool live = rec < B;
+    const int bi = live ? band[rec] : 0;
+    const bool owner = k < 8;                         // holds z[k]
+    const double b0 = tabs->ba[bi][0];
+    const double bk = owner ? tabs->ba[bi][k + 1] : 0.0, ak = owner ? tabs->ba[bi][9 + k + 1] : 0.0;
+    double z = 0.0;
+    // staging: the 16 lanes of a row cover 32 samples of their record, two each
+    float2 pre;
+    auto fetch = [&](int t0) {
+        float v0 = 0.0f, v1 = 0.0f;
+        const int t = t0 + 2 * k;
+        if (live) {
+            if (I16) {
+                const int16_t* f = (const int16_t*)frames + rec * T;
+                if (t < T) v0 = (float)f[t] * (1.0f / 32768.0f);          // PCM16 as soundfile.read hands it to the reference: exact in float32
+                if (t + 1 < T) v1 = (float)f[t + 1] * (1.0f / 32768.0f);
+            } else {
+                const float* f = (const float*)frames + rec * T;
+                if (t < T) v0 = f[t];
+                if (t + 1 < T) v1 = f[t + 1];
+            }
+        }
+        pre = make_float2(v0, v1);
+    };
+    fetch(0);
+    // the neighbour register: written by the row_shl:1 moves in lanes 0..6, never in lane 7 (its source lane is off) -> stays -0.0 there
+    uint32_t nb_lo = 0u, nb_hi = 0x80000000u;
+    for (int t0 = 0; t0 < T; t0 += BR_TT) {
+        s_x[row][2 * k] = (double)pre.x; s_x[row][2 * k + 1] = (double)pre.y;
+        wave_fence_lds();
+        if (t0 + BR_TT < T) fetch(t0 + BR_TT);          // in flight while this tile is filtered
+        if (owner) {
+            // samples past the end of the record are zeros (their outputs are never stored): the tile is always walked in full
+            #pragma unroll 1
+            for (int tb = 0; tb < BR_TT; tb += 8) {
+                double xs[8], ys[8];
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) xs[u] = s_x[row][tb + u];
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double xn = xs[u];
+                    const double t = xn * bk;                                       // b[k+1] x
+                    const double yn = z + b0 * xn;                                  // lane 0: y = z[0] + b[0] x
+#if ES_BPF_ROW_FMAC
+                    // a[k+1] y with y taken from lane 0 of the row INSIDE the multiply: v_fmac_f64_dpp (the one float64 arithmetic instruction
+                    // that takes a DPP operand) onto -0.0 -- fma(y, a, -0.0) is the correctly rounded product, signed zeros included -- so that
+                    // the broadcast is not a link of its own in the sample-to-sample dependency chain (add -> multiply -> subtract)
+                    double va = -0.0;
+                    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(va) : "v"(yn), "v"(ak));
+#else
+                    const double yb = __builtin_amdgcn_update_dpp(yn, yn, 0x150, 0xf, 0xf, false);      // row_newbcast:0 (every active lane is written: `old` is never kept)
+                    const double va = yb * ak;
+#endif
+                    uint64_t zu; __builtin_memcpy(&zu, &z, 8);
+                    nb_lo = (uint32_t)__builtin_amdgcn_update_dpp((int)nb_lo, (int)(uint32_t)zu, 0x101, 0xf, 0xf, false);          // row_shl:1: lane k <- lane k+1
+                    nb_hi = (uint32_t)__builtin_amdgcn_update_dpp((int)nb_hi, (int)(uint32_t)(zu >> 32), 0x101, 0xf, 0xf, false);
+                    const uint64_t nu = ((uint64_t)nb_hi << 32) | nb_lo;
+                    double z_nb; __builtin_memcpy(&z_nb, &nu, 8);
+                    z = (z_nb + t) - va;                                            // z[k] = (z[k+1] + b[k+1] x) - a[k+1] y
+                    ys[u] = yn;
+                }
+                if (k == 0) {
+                    #pragma unroll
+                    for (int u = 0; u < 8; ++u) s_y[row][tb + u] = ys[u];
+                }
+            }
+        }
+        wave_fence_lds();
+        if (live) {
+            #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = t0 + 2 * k + h;
+                if (t < T) {
+                    const double v = s_y[row][2 * k + h];
+                    y[rec * T + t] = v;
+                    if (y32) y32[rec * T + t] = (float)v;
+                }
+            }
+        }
+        wave_fence_lds();
+    }
+}
+
 // ---------------------------------------------------------------------------------------- xcorr
 // One WAVE per (record, segment of 64 x 19 = 1216 lags).  The 1216 + 62 samples the segment needs
 // are staged in LDS with coalesced 8-byte loads; lane l then owns the chunk of XC_R = 19
@@ -480,6 +591,17 @@ __global__ __launch_bounds__(NT) void es_pick_kernel(const double* __restrict__ 
 int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, const uint8_t* band,
                   double* y, float* y32, hipStream_t st)
 {
+    // sixteen lanes per record (nine instead of seventeen vector instructions per sample and wave) while the batch cannot fill the chip with
+    // the four-lanes-per-record kernel anyway: up to four such waves per SIMD
+    if (B <= (long long)ctx->num_cu * 4 * 4 * BR_RECS / 4) {
+        const unsigned blocks = (unsigned)((B + BR_RECS - 1) / BR_RECS);
+        if (dtype == ES_DTYPE_I16)
+            hipLaunchKernelGGL(es_bpf_row_kernel<true>, dim3(blocks), dim3(64), 0, st, frames, (long long)B, T, band, ctx->d_tables, y, y32);
+        else
+            hipLaunchKernelGGL(es_bpf_row_kernel<false>, dim3(blocks), dim3(64), 0, st, frames, (long long)B, T, band, ctx->d_tables, y, y32);
+        ES_HIP_CHECK(ctx, hipGetLastError());
+        return ES_OK;
+    }
     if (B < 262144) {                               // four lanes per record: 4x the waves
         const long long per_block = (long long)BQ_RECS * BQ_WAVES;
         const unsigned blocks = (unsigned)((B + per_block - 1) / per_block);

@@ -121,28 +121,35 @@ class WatermarkDetector:
             for i, sc in zip(idx, self._scan_prepare([signals[i] for i in idx], order)):
                 scans[i] = sc
         # Decoding is stateless (the validator's verdict depends on blob and counter only; nonce bookkeeping happens on the host, in
-        # _accept), so it can be batched across clips; the WALK is clip by clip and band by band, in the reference's order with its
-        # early returns.  Band rank r of a clip is decoded when the walk first needs it, together with rank r of every later clip of
-        # the group whose earlier ranks are already known to hold no decodable blob at all (those clips are certain to reach rank r):
-        # one demodulate + list-decode + validate batch per band rank in the common cases, never the 4 x 400 candidates x 4 variants
-        # of every band of every clip up front.
+        # _accept), so it is batched ahead of the walk; the WALK is clip by clip and band by band, in the reference's order with its
+        # early returns.  When the walk needs a (clip, band) that is not decoded yet, that band and -- in walk order: the clip's
+        # further bands, then the later clips of the group -- as many further ones as fit under a cap on the candidates per batch go
+        # through ONE demodulate + list-decode + validate batch.  A lone clip (a few hundred candidates) is decoded in one batch,
+        # as before; a hundred unwatermarked clips at list size 256 (4 x 400 candidates x 4 variants each) no longer ask for
+        # gigabytes of candidate rows at once, and what an early return makes unnecessary is bounded by the cap.
         plans: dict[int, list] = {i: [self._scan_plan(scans[i], bi) for bi in range(len(order))] for i in range(len(signals)) if scans[i] is not None}
         cache: dict[tuple[int, int], list] = {}
         group_of = {i: idx for idx in groups.values() for i in idx}
-
-        def hopeless(i: int, upto: int) -> bool:          # ranks < upto decoded and without a single blob: the clip will reach rank `upto`
-            return all((i, r) in cache and not any(b is not None for blobs in cache[(i, r)] for b in blobs) for r in range(upto))
+        cap = self._pair_cap()
 
         def need(i: int, bi: int) -> list:
             if (i, bi) not in cache:
-                batch = [i] + [j for j in group_of[i] if j > i and scans[j] is not None and (j, bi) not in cache and hopeless(j, bi)]
-                flat = [(j, p) for j in batch for p in plans[j][bi][0]]
+                todo = [(i, r) for r in range(bi, len(order))] + [(j, r) for j in group_of[i] if j > i and scans[j] is not None for r in range(len(order))]
+                batch, n = [], 0
+                for (j, r) in todo:
+                    if (j, r) in cache:
+                        continue
+                    m = len(plans[j][r][0])
+                    if batch and n + m > cap:
+                        break
+                    batch.append((j, r)); n += m
+                flat = [(j, p) for (j, r) in batch for p in plans[j][r][0]]
                 res = self._decode_pairs_grouped([(scans[j]["frames"], p[0], p[2]) for j, p in flat]) if flat else []
                 at = 0
-                for j in batch:
-                    n = len(plans[j][bi][0])
-                    cache[(j, bi)] = res[at:at + n]
-                    at += n
+                for (j, r) in batch:
+                    m = len(plans[j][r][0])
+                    cache[(j, r)] = res[at:at + m]
+                    at += m
             return cache[(i, bi)]
 
         out = []
@@ -348,10 +355,14 @@ class WatermarkDetector:
             k = m
         return out
 
+    def _pair_cap(self) -> int:
+        """(frame, counter) pairs per decode launch: at most 2^18 list paths per sign / PN variant (1 024 pairs at the default list
+        size 256 -- the candidate rows of one launch are then 58 MB --, 32 768 at list size 8)."""
+        return max(64, (1 << 18) // max(1, self._list_size))
+
     def _decode_pairs(self, frames, rows, ctrs) -> list[list[bytes | None]]:
-        """Chunked front of _decode_pairs_chunk: at most 2^18 list paths per variant and launch (1 024 pairs at the default
-        list size 256: cand_info of one chunk is 58 MB), so that a long candidate list never asks for gigabytes at once."""
-        cap = max(64, (1 << 18) // max(1, self._list_size))
+        """Chunked front of _decode_pairs_chunk, so that a long candidate list never asks for gigabytes at once."""
+        cap = self._pair_cap()
         if len(ctrs) <= cap:
             return self._decode_pairs_chunk(frames, rows, ctrs)
         out: list = []

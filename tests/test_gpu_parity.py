@@ -142,6 +142,41 @@ def test_sync_and_llr_match_reference_golden(engine, golden_detector):
         assert np.max(np.abs(ls[i].cpu().numpy() - g[f"{t}/llr_short700"])) <= 1e-5
 
 
+def test_bandpass_bits_all_kernels(engine, oracle):
+    """The three band-pass kernels (sixteen lanes per record for small batches, four lanes per record, one lane per record for huge
+    batches) against the oracle's lfilter BIT FOR BIT (uint64 view: signed zeros count): random, silence, negative zeros, sparse
+    impulses (delay elements pass through +-0), denormals, a long record."""
+    ba, tpl, taps, ntaps, _ = pack_tables()
+    rng = np.random.default_rng(77)
+
+    def rows(n, T):
+        x = rng.normal(0, 0.2, (n, T)).astype(np.float32)
+        x[1 % n] = 0.0
+        x[2 % n] = -0.0
+        x[3 % n] = 0.0; x[3 % n, ::37] = rng.choice(np.array([-1.0, 1.0, 0.5], np.float32), x[3 % n, ::37].shape)
+        x[4 % n] = np.where(rng.random(T) < 0.5, np.float32(0.0), np.float32(-0.0)); x[4 % n, T // 2] = 1e-3
+        x[5 % n] = (rng.normal(0, 1, T) * 1e-42).astype(np.float32)            # float32 denormals
+        return x
+
+    def check(x, band, idx):
+        f, b = _dev(engine, x, band)
+        y = engine.bpf(f, b).cpu().numpy()
+        y2, y32 = engine.bpf2(f, b)
+        assert np.array_equal(y2.cpu().numpy().view(np.uint64), y.view(np.uint64))
+        assert np.array_equal(y32.cpu().numpy().view(np.uint32), y.astype(np.float32).view(np.uint32))
+        for i in idx:
+            ref = oracle.lfilter(ba[band[i], :9], ba[band[i], 9:], x[i])
+            assert np.array_equal(ref.view(np.uint64), y[i].view(np.uint64)), (x.shape, i)
+
+    for n, T in ((7, 100), (6, 1215), (3, 20011)):                       # sixteen lanes per record
+        check(rows(n, T), (np.arange(n) % 4).astype(np.uint8), range(n))
+    x = rows(5003, 300)                                                   # four lanes per record
+    check(x, (np.arange(5003) % 4).astype(np.uint8), list(range(8)) + [63, 64, 4097, 5002])
+    x = rows(8, 64)                                                       # one lane per record (>= 262 144 records)
+    big = np.tile(x, (32768 + 1, 1))[:262144 + 5]
+    check(big, (np.arange(big.shape[0]) % 4).astype(np.uint8), list(range(8)) + [262143, 262148])
+
+
 def test_edge_records(engine, oracle):
     ba, tpl, taps, ntaps, _ = pack_tables()
     rng = np.random.default_rng(8)
@@ -670,6 +705,58 @@ def test_scl_multi_frames_per_wave(engine, oracle, L):
         assert np.array_equal(np.packbits(ci[:nn], axis=1), got.cand_info[i, :nn].cpu().numpy())
         assert np.array_equal(cm[:nn], got.cand_metric[i, :nn].cpu().numpy())
         assert np.array_equal(cc[:nn], got.cand_ok[i, :nn].cpu().numpy())
+
+
+@pytest.mark.parametrize("L", [1, 8, 32])
+def test_scl_softplus_fallback_ranges(engine, oracle, L):
+    """Operands that leave the straight-line softplus of the list decoders: |t| >= 512 (sums of many +-12 LLRs, float64 LLRs of
+    magnitude up to 400 -- exp underflows to subnormals and to zero), and 1 + e^t within 3 * 2^-20 below 2 (operands that differ by
+    ~1e-7: fdlibm's |f| < 2^-20 corner).  The hot loops only flag such lanes and redo the evaluation with the generic form outside
+    the loop; every mapping must still equal the oracle bit for bit."""
+    rng = np.random.default_rng(900 + L)
+    rows = []
+    for k in range(24):
+        kind = k % 6
+        if kind == 0:                                   # all +-12: |g| doubles per level, 768 at depth 6
+            v = rng.choice([-12.0, 12.0], 1024)
+        elif kind == 1:                                 # near-equal halves at every stride: tiny non-zero differences / sums
+            base = np.clip(rng.normal(0, 3, 1024), -12, 12)
+            v = base.copy()
+            for st in (512, 256, 128):
+                idx = np.arange(1024)
+                m = (idx // st) % 2 == 1
+                v[m] = v[idx[m] - st] * rng.choice([-1.0, 1.0]) + rng.normal(0, 2e-7, int(m.sum()))
+        elif kind == 2:                                 # big float64 magnitudes: sums beyond 708 and 745
+            v = rng.normal(0, 150, 1024)
+        elif kind == 3:                                 # a real codeword at magnitude 12 with a few flips
+            info = rng.integers(0, 256, (1, 55), dtype=np.uint8)
+            code = engine.polar_encode(torch.from_numpy(info).to(engine.device)).cpu().numpy()[0]
+            v = (code * 2.0 - 1.0) * 12.0
+            v[rng.choice(1024, 30, replace=False)] *= -1
+        elif kind == 4:                                 # mixed: strong and tiny
+            v = rng.choice([-300.0, -12.0, -1e-7, 1e-7, 12.0, 300.0], 1024)
+        else:
+            v = np.clip(rng.normal(0, 40, 1024), -400, 400)
+        rows.append(v)
+    llr = np.stack(rows)
+    x = torch.from_numpy(llr).to(engine.device)          # float64 input
+    outs = []
+    for multi, lanes in ((0, 4), (1, 4), (1, 2), (1, 1)):
+        engine.set_option("scl_multi", multi); engine.set_option("scl_lanes", lanes)
+        try:
+            outs.append(engine.scl(x, list_size=L, skip_if_hard_ok=False))
+        finally:
+            engine.set_option("scl_multi", -1); engine.set_option("scl_lanes", 0)
+    for o in outs[1:]:
+        for name in ("hard_info", "hard_ok", "ncand", "cand_info", "cand_metric", "cand_ok"):
+            assert torch.equal(getattr(outs[0], name), getattr(o, name)), (name, L)
+    got = outs[-1]
+    for i in range(llr.shape[0]):
+        nn, ci, cm, cc = oracle.scl_list(llr[i], L)
+        assert int(got.ncand[i]) == nn, i
+        assert np.array_equal(np.packbits(ci[:nn], axis=1), got.cand_info[i, :nn].cpu().numpy()), i
+        assert np.array_equal(cm[:nn].view(np.uint64), got.cand_metric[i, :nn].cpu().numpy().view(np.uint64)), i
+        assert np.array_equal(cc[:nn], got.cand_ok[i, :nn].cpu().numpy()), i
 
 
 def test_llr_shift_search_screen_is_exact(engine, oracle):

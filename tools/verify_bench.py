@@ -24,3 +24,11 @@ clips = [tx.process((0.05 * rng.standard_normal(5 * 48000)).astype(np.float32)) 
 det.verify_batch(clips, 48000); torch.cuda.synchronize()
 t0 = time.perf_counter(); res = det.verify_batch(clips, 48000); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"verify_batch(8 clips of 5 s, list 8): {dt * 1e3:.1f} ms total, {dt * 1e3 / 8:.1f} ms per clip -> {res}")
+# stage split of the sync of one 5 s clip (four bands): band-pass, correlation + threshold / peaks
+eng = det.engine
+x = torch.from_numpy(np.repeat(audio[None, :], 4, axis=0)).to(eng.device)
+bid = torch.arange(4, dtype=torch.uint8, device=eng.device)
+for name, fn in (("band-pass (4 records x 240 000 samples)", lambda: eng.bpf(x, bid)), ("sync (band-pass + correlation + threshold / peaks)", lambda: eng.sync(x, bid, keep_corr=False))):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"{name}: {dt * 1e3:.2f} ms")
