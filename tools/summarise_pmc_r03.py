@@ -34,7 +34,8 @@ wave_cyc = c["SQ_WAVE_CYCLES"] * 4
 out = {
     "source": f"rocprofv3 --pmc, one pass per counter group, counters only (tools/collect_pmc_r03.sh {TAG}) -- python3 tools/scl_pmc3.py '' 65536 8; MI355X, round 3; "
               "SQ_* cycle counters are in quad-cycles, GRBM_GUI_ACTIVE sums the 8 XCDs; means over 3 warm launches",
-    "kernel": "es_scl_wide_kernel<64,8>, B = 65 536 frames, 8 192 one-wave blocks, three waves per SIMD",
+    "kernel": "es_scl_wide_kernel<64,8>, B = 65 536 frames, 8 192 one-wave blocks, three waves per SIMD"
+              + {"base": " -- the kernel as it stood at the START of round 3 (= round 2's)", "final": " -- the kernel as shipped at the end of round 3"}.get(TAG, ""),
     "raw": {k: c[k] for k in sorted(c)},
     "per_frame": {"valu_instructions": round(valu / B), "fp64_instructions": round(fp64 / B), "trans_f64_instructions": round(trans / B),
                   "int_instructions": round(ints / B), "cvt_instructions": round(c["SQ_INSTS_VALU_CVT"] / B),
@@ -58,6 +59,6 @@ out = {
     "issue_slot_fraction_mixed_ceiling": (fp64 * cyc["fp64"] + trans * cyc["trans_f64"] + other * cyc["other"]) / 1024.0 / gui,
     "hbm_side_GBps_at_this_launch": (fetch_b + write_b) / (gui / 2.4e9) / 1e9,
 }
-name = "r03_scl_pmc.json" if TAG == "base" else f"r03_scl_pmc_{TAG}.json"
+name = {"final": "r03_scl_pmc.json", "base": "r03_scl_pmc_before.json"}.get(TAG, f"r03_scl_pmc_{TAG}.json")
 json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "raw"}, indent=1))
