@@ -250,8 +250,18 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     double r = ES_FMA(kd, ES_EXP_NLN2HI, t);
     r = ES_FMA(kd, ES_EXP_NLN2LO, r);
     const uint32_t idx = 2u * (uint32_t)(ki & 127u);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ES_EXP_TAB_LDS_ADDR)
+    /* the including kernel keeps its copy of the table at a KNOWN LDS address (it checks that at run time): the entry's address is then
+       the scaled index itself, without the add of a link-time base that the compiler does not fold (one instruction per evaluation) */
+    typedef __attribute__((address_space(3))) const uint64_t es_lds_u64;
+    es_lds_u64* const te = (es_lds_u64*)(uint32_t)((ES_EXP_TAB_LDS_ADDR) + idx * 8u);
+    const double tail = es_u2d(te[0]);
+    const uint64_t sbits = te[1] + (ki << 45);
+    (void)tab;
+#else
     const double tail = es_u2d(tab[idx]);
     const uint64_t sbits = tab[idx + 1] + (ki << 45);
+#endif
     const double p23 = ES_FMA(r, ES_EXP_C3, ES_EXP_C2);
     const double tr = r + tail;
     const double r2 = r * r;

@@ -36,11 +36,17 @@
 // Blocks are not persistent: a block decodes its frames and leaves; its slab slot comes from a bitmap (as in es_scl_multi.hip).
 //
 // Values are bit-identical to the reference list decoder for the same reason as in es_scl.hip (es_math.h).
+// This file's kernels use dynamic LDS only, with the exp table first in it: the table sits at LDS address 0 (checked at kernel start),
+// which lets es_math.h address its entries without adding a base.
+#define ES_EXP_TAB_LDS_ADDR 0u
 #include "es_scl_common.h"
 #ifndef ES_WIDE_GBATCH
 #define ES_WIDE_GBATCH 8                          /* load pairs in flight in the lane-serial g loops (divides 8; 8: +1 % over 4, measured) */
 #endif
 
+#ifndef ES_WIDE_WPS
+#define ES_WIDE_WPS 3                             /* waves per SIMD the kernel is compiled for (168 VGPRs at 3) */
+#endif
 #ifndef ES_WIDE_FUSE_GF
 #define ES_WIDE_FUSE_GF 1                         /* 1: the g at the top of a step and the f level below it in one pass (slab levels 2..6); 3: also pairs of f levels */
 #endif
@@ -306,7 +312,7 @@ __device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long f
 // L lanes per block, LF paths per frame.  LF > 64: one frame per block, the block is the group (barrier = __syncthreads).
 // LF <= 64: every wave is a group of 64 / LF whole frames (barrier = wave fence), L / LF frames per block.
 template <int L, int LF>
-__global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
+__global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
 {
     constexpr bool WAVE = (LF <= 64);                // the block is one wave
     constexpr int FRG = L / LF;                      // frames per block
@@ -319,6 +325,9 @@ __global__ __launch_bounds__(L, 3) void es_scl_wide_kernel(WideArgs a)
     const int lane = p & 63, wv = p >> 6;
     const int pl = p % LF;                           // path within its frame
     const int fp0 = p - pl;                          // slot of the frame's path 0
+    using WLds = WideLds<L, NB>;
+    static_assert(__builtin_offsetof(WLds, exp_tab) == 0, "the exp table must be the first member (ES_EXP_TAB_LDS_ADDR)");
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != ES_EXP_TAB_LDS_ADDR) __builtin_trap();   // never: no static LDS in this file
     for (int i = p; i < ES_EXP_TAB_WORDS; i += L) W.exp_tab[i] = a.exp_tab[i];
     __syncthreads();
     auto group_sync = [&]() { if constexpr (WAVE) wave_fence_global(); else __syncthreads(); };
@@ -815,7 +824,7 @@ size_t es_scl_wide_scratch_bytes(const es_ctx* ctx, int* slots_out)
 {
     if (!ctx->wide_enabled) { *slots_out = 0; return 0; }
     const size_t Lm = (size_t)es_wide_lanes_max(ctx);
-    const int slots = ctx->num_cu * 3 * (int)(256 / Lm);          // twelve waves per CU
+    const int slots = ctx->num_cu * ES_WIDE_WPS * (int)(256 / Lm);          // 4 x ES_WIDE_WPS waves per CU
     *slots_out = slots;
     return (size_t)slots * (N * Lm * sizeof(double) + (size_t)WIDE_AUX_PER_PATH * Lm);
 }
