@@ -12,8 +12,8 @@ path over one batch of 65 536 synthetic windows per GPU, already resident in HBM
 holding one frame (ctr = i, key 0xAA*32) resampled by U[0.95, 1.05], at a uniform offset, in AWGN at -15 dB;
 band-pass -> fused sync (float32 NCC screen in LDS + exact median/MAD threshold + NMS / top-5, one kernel) -> _llr (variant 0)
 at the DETECTED peak -> Polar(1024,448) SCL-8 (validator None) -> candidate selection.  One window = one frame record, so
-`value` is frames/s.  Steps alternate between two pipeline lanes (HIP streams), so that the front end of one step runs
-beside the list decoder of the other.  N > 1: weak scaling -- rank r decodes its own 65 536 windows (counters
+`value` is frames/s.  Steps rotate over four pipeline lanes (HIP streams, one context each), so that the front ends of some steps run
+beside the list decoders of others.  N > 1: weak scaling -- rank r decodes its own 65 536 windows (counters
 [r * 65 536, (r + 1) * 65 536)); rank 0 derives the key/PN schedule of all counters and broadcasts it once (RCCL) before the
 timed region; the data path has no collective.  At --steps 20 the timed region is ~0.5 s of steady work.
 
@@ -76,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--windows", type=int, default=65536, help="C3 windows per GPU per step (BASELINE config 3 = 65 536)")
     ap.add_argument("--list-size", type=int, default=8)
     ap.add_argument("--legs", default="auto", help="comma list of c2,c2_lanes,c3_unfused,c4,c5 (auto: all at N = 1, c2 + c4 at N > 1; none: headline only)")
-    ap.add_argument("--big-lanes", type=int, default=2, help="pipeline lanes of the headline and of the c4 leg (launches of 65 536 records)")
+    ap.add_argument("--big-lanes", type=int, default=4, help="pipeline lanes of the headline and of the c4 leg (launches of 65 536 records): up to 8")
     ap.add_argument("--frames", type=int, default=1024, help="frame records per batch of the c2 legs (C2 = 1024)")
     ap.add_argument("--c2-steps", type=int, default=480)
     ap.add_argument("--group", type=int, default=16, help="c2: batches per list-decoder launch of the grouped pipeline")
@@ -235,7 +235,10 @@ def run_rank(a) -> None:
     # Eight hardware queues: every pipeline of this process runs on the SAME seven streams (four front-end streams at high priority,
     # two list-decoder / big-launch streams, one spare for the seven-lane leg)
     front_streams = pipeline_streams(dev, a.front_lanes, priority=-1)
-    back_streams = pipeline_streams(dev, max(a.scl_streams, a.big_lanes))
+    back_streams = pipeline_streams(dev, max(a.scl_streams, min(a.big_lanes, 8 - a.front_lanes)))
+    big_streams = (back_streams + front_streams)[:a.big_lanes]                # the lanes of the 65 536-record launches
+    if len(big_streams) < a.big_lanes:
+        raise SystemExit(f"--big-lanes {a.big_lanes}: the process keeps {len(back_streams) + len(front_streams)} streams (GPU_MAX_HW_QUEUES = 8)")
     out_legs = {}
 
     # ============================================================ headline: C3, weak scaling
@@ -262,7 +265,7 @@ def run_rank(a) -> None:
     win, off = WL.c3_windows_device(clean, seed=34 + rank)     # ... resampled, offset, in noise
     del clean
 
-    pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=back_streams[:a.big_lanes])
+    pipe3 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=big_streams)
     for e in pipe3.lane_engs:                                   # kernels by launch size: 65 536 records -> one lane per path
         e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
     ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -465,7 +468,7 @@ def run_rank(a) -> None:
         ok4 = torch.empty(n4, dtype=torch.int8, device=dev)
         peak4 = torch.empty(n4, dtype=torch.int32, device=dev)
         chunk = max(1, min(a.c4_chunk, n4))
-        pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=back_streams[:a.big_lanes])
+        pipe4 = DecodePipeline(eng, list_size=L, lanes=a.big_lanes, streams=big_streams)
         for e in pipe4.lane_engs:
             e.set_option("scl_multi", -1); e.set_option("scl_lane_slab", 1)
 
@@ -521,8 +524,8 @@ def run_rank(a) -> None:
                        "world_size": world, "backend": ("nccl (RCCL)" if a.backend == "nccl" else a.backend) if world > 1 else "none (single rank)",
                        "sharding": f"{world} x {Bw} windows per step (rank r: counters [r*{Bw}, (r+1)*{Bw})); schedule of all {total} counters derived on rank 0, "
                                    f"one broadcast before the timed region ({total * 153} B, {bcast_s:.4f} s incl. derivation)",
-                       "pipelining": f"steps alternate between {a.big_lanes} pipeline lanes (HIP streams, one context each): the front end of one step runs beside the "
-                                     f"list decoder of the other; one list-decoder launch of {Bw} frames per step (one lane per path, 64/L frames per wave)",
+                       "pipelining": f"steps rotate over {a.big_lanes} pipeline lanes (HIP streams, one context each): the front ends of some steps run beside the "
+                                     f"list decoders of others; one list-decoder launch of {Bw} frames per step (one lane per path, 64/L frames per wave)",
                        "untimed_preparation": "one step per lane (first launches allocate scratch and upload code), then the --warmup steps; the garbage collector is off inside the timed region",
                        "host_enqueue_ms_of_the_timed_steps": 1e3 * host_enqueue_s, "timed_region_ms": 1e3 * dt,
                        "stage_ms_one_step_alone": stage_ms, "results_identical_to_a_sequential_pass": same_as_seq,

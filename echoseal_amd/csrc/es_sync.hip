@@ -205,6 +205,12 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void es_bpf_quad_kernel(const void* 
 // Lane 7 has no upper neighbour: its source lane 8 is disabled, so the move leaves lane 7's register at the -0.0 it was given at the
 // start and -0.0 + t == t for every t, signed zeros included (an exact "no neighbour").  Arithmetic and its order are SciPy's
 // direct-form-II-transposed loop (separate multiply and add), as in the other two kernels; bit-exactness is pinned by the same tests.
+#ifndef ES_BPF_ROW_TWO_WAVES
+#define ES_BPF_ROW_TWO_WAVES 1                      /* the recursion's wave does no global memory traffic: a second wave of the block loads and stores */
+#endif
+#ifndef ES_BPF_ROW2_UNROLL
+#define ES_BPF_ROW2_UNROLL 1
+#endif
 #ifndef ES_BPF_ROW_FMAC
 #define ES_BPF_ROW_FMAC 0                          /* 1: a[k+1] y through v_fmac_f64_dpp (same bits, same speed: measured) */
 #endif
@@ -303,6 +309,120 @@ __global__ __launch_bounds__(64) void es_bpf_row_kernel(const void* __restrict__
             }
         }
         wave_fence_lds();
+    }
+}
+
+// ---------------------------------------------------------------------------------------- BPF (row, two waves)
+// The same recursion with the memory traffic taken OUT of the recursion's wave: in the one-wave form the wait for the prefetched samples
+// is an `s_waitcnt vmcnt(0)` (the stores of the previous tile sit behind conditional branches, so the compiler cannot count them), i.e. once
+// per 32 samples the recursion stands still until the previous tile's stores are acknowledged -- a third of the time on long records.
+// Here a block is two waves: wave 1 loads tile k+1 into LDS and stores tile k-1 from LDS while wave 0 filters tile k (LDS to LDS); one
+// workgroup barrier per tile.  Arithmetic, lane roles and the -0.0 neighbour of lane 7 exactly as in es_bpf_row_kernel.
+template <bool I16>
+__global__ __launch_bounds__(128) void es_bpf_row2_kernel(const void* __restrict__ frames,
+        long long B, int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
+        double* __restrict__ y, float* __restrict__ y32)
+{
+    __shared__ double s_x[2][BR_RECS][BR_TT];
+    __shared__ double s_y[2][BR_RECS][BR_TT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __builtin_amdgcn_s_setprio(3);
+    const long long rec0 = (long long)blockIdx.x * BR_RECS;
+    const int row = lane >> 4, k = lane & 15;
+    const long long rec = rec0 + row;
+    const bool live = rec < B;
+    const int ntiles = (T + BR_TT - 1) / BR_TT;
+    if (wv == 1) {
+        // ---- the I/O wave: tile kt+1 in, tile kt-1 out, while the other wave filters tile kt
+        auto fetch = [&](int t0, float& v0, float& v1) {
+            v0 = 0.0f; v1 = 0.0f;
+            const int t = t0 + 2 * k;
+            if (live) {
+                if (I16) {
+                    const int16_t* f = (const int16_t*)frames + rec * T;
+                    if (t < T) v0 = (float)f[t] * (1.0f / 32768.0f);          // PCM16 as soundfile.read hands it to the reference: exact in float32
+                    if (t + 1 < T) v1 = (float)f[t + 1] * (1.0f / 32768.0f);
+                } else {
+                    const float* f = (const float*)frames + rec * T;
+                    if (t < T) v0 = f[t];
+                    if (t + 1 < T) v1 = f[t + 1];
+                }
+            }
+        };
+        float a0, a1;
+        fetch(0, a0, a1);
+        s_x[0][row][2 * k] = (double)a0; s_x[0][row][2 * k + 1] = (double)a1;
+        if (ntiles > 1) fetch(BR_TT, a0, a1);
+        __syncthreads();                                           // tile 0 is staged
+        for (int kt = 0; kt < ntiles; ++kt) {
+            if (kt + 1 < ntiles) { s_x[(kt + 1) & 1][row][2 * k] = (double)a0; s_x[(kt + 1) & 1][row][2 * k + 1] = (double)a1; }
+            if (kt + 2 < ntiles) fetch((kt + 2) * BR_TT, a0, a1);
+            if (kt >= 1 && live) {                                 // tile kt-1 was finished before the last barrier
+                #pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int t = (kt - 1) * BR_TT + 2 * k + h;
+                    if (t < T) {
+                        const double v = s_y[(kt - 1) & 1][row][2 * k + h];
+                        y[rec * T + t] = v;
+                        if (y32) y32[rec * T + t] = (float)v;
+                    }
+                }
+            }
+            __syncthreads();                                       // tile kt filtered, tile kt+1 staged
+        }
+        if (live) {
+            #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = (ntiles - 1) * BR_TT + 2 * k + h;
+                if (t < T) {
+                    const double v = s_y[(ntiles - 1) & 1][row][2 * k + h];
+                    y[rec * T + t] = v;
+                    if (y32) y32[rec * T + t] = (float)v;
+                }
+            }
+        }
+        return;
+    }
+    // ---- the recursion wave
+    const int bi = live ? band[rec] : 0;
+    const bool owner = k < 8;                         // holds z[k]
+    const double b0 = tabs->ba[bi][0];
+    const double bk = owner ? tabs->ba[bi][k + 1] : 0.0, ak = owner ? tabs->ba[bi][9 + k + 1] : 0.0;
+    double z = 0.0;
+    uint32_t nb_lo = 0u, nb_hi = 0x80000000u;         // -0.0: what lane 7 keeps as its "neighbour" (see es_bpf_row_kernel)
+    __syncthreads();                                  // tile 0 is staged
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (owner) {
+#if ES_BPF_ROW2_UNROLL
+            #pragma unroll                                          // all of the tile's LDS reads can be issued ahead of the recursion
+#else
+            #pragma unroll 1
+#endif
+            for (int tb = 0; tb < BR_TT; tb += 8) {
+                double xs[8], ys[8];
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) xs[u] = s_x[kt & 1][row][tb + u];
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double xn = xs[u];
+                    const double t = xn * bk;                                       // b[k+1] x
+                    const double yn = z + b0 * xn;                                  // lane 0: y = z[0] + b[0] x
+                    const double yb = __builtin_amdgcn_update_dpp(yn, yn, 0x150, 0xf, 0xf, false);      // row_newbcast:0
+                    uint64_t zu; __builtin_memcpy(&zu, &z, 8);
+                    nb_lo = (uint32_t)__builtin_amdgcn_update_dpp((int)nb_lo, (int)(uint32_t)zu, 0x101, 0xf, 0xf, false);          // row_shl:1
+                    nb_hi = (uint32_t)__builtin_amdgcn_update_dpp((int)nb_hi, (int)(uint32_t)(zu >> 32), 0x101, 0xf, 0xf, false);
+                    const uint64_t nu = ((uint64_t)nb_hi << 32) | nb_lo;
+                    double z_nb; __builtin_memcpy(&z_nb, &nu, 8);
+                    z = (z_nb + t) - yb * ak;                                       // z[k] = (z[k+1] + b[k+1] x) - a[k+1] y
+                    ys[u] = yn;
+                }
+                if (k == 0) {
+                    #pragma unroll
+                    for (int u = 0; u < 8; ++u) s_y[kt & 1][row][tb + u] = ys[u];
+                }
+            }
+        }
+        __syncthreads();                                           // tile kt filtered, tile kt+1 staged
     }
 }
 
@@ -595,10 +715,17 @@ int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, 
     // the four-lanes-per-record kernel anyway: up to four such waves per SIMD
     if (B <= (long long)ctx->num_cu * 4 * 4 * BR_RECS / 4) {
         const unsigned blocks = (unsigned)((B + BR_RECS - 1) / BR_RECS);
+#if ES_BPF_ROW_TWO_WAVES
+        if (dtype == ES_DTYPE_I16)
+            hipLaunchKernelGGL(es_bpf_row2_kernel<true>, dim3(blocks), dim3(128), 0, st, frames, (long long)B, T, band, ctx->d_tables, y, y32);
+        else
+            hipLaunchKernelGGL(es_bpf_row2_kernel<false>, dim3(blocks), dim3(128), 0, st, frames, (long long)B, T, band, ctx->d_tables, y, y32);
+#else
         if (dtype == ES_DTYPE_I16)
             hipLaunchKernelGGL(es_bpf_row_kernel<true>, dim3(blocks), dim3(64), 0, st, frames, (long long)B, T, band, ctx->d_tables, y, y32);
         else
             hipLaunchKernelGGL(es_bpf_row_kernel<false>, dim3(blocks), dim3(64), 0, st, frames, (long long)B, T, band, ctx->d_tables, y, y32);
+#endif
         ES_HIP_CHECK(ctx, hipGetLastError());
         return ES_OK;
     }
