@@ -177,6 +177,39 @@ def test_bandpass_bits_all_kernels(engine, oracle):
     check(big, (np.arange(big.shape[0]) % 4).astype(np.uint8), list(range(8)) + [262143, 262148])
 
 
+def test_pick_threshold_saturation_shortcut(engine, oracle):
+    """es_pick_batch proves `thr == 0.95` from one histogram pass where it can and takes the exact order statistics where it cannot:
+    rows on both sides of the saturation boundary (4.5 sigma ~ 0.95 for Gaussian rows), shifted medians, values at +-1, an even and an odd
+    length, a 240 000-lag row (one band of a 5 s recording), a row with a NaN -- threshold, peak list and fallback flag equal the oracle's."""
+    rng = np.random.default_rng(2024)
+    rows = []
+    for n in (4096, 4097):
+        for sigma in (0.05, 0.15, 0.19, 0.205, 0.2105, 0.2115, 0.215, 0.23, 0.3, 0.6):
+            rows.append(np.clip(rng.normal(0.0, sigma, n), -1.0, 1.0))
+        rows.append(np.clip(rng.normal(0.3, 0.25, n), -1.0, 1.0))
+        rows.append(np.clip(rng.normal(-0.4, 0.3, n), -1.0, 1.0))
+        r = np.clip(rng.normal(0.0, 0.25, n), -1.0, 1.0); r[::50] = 1.0; r[7::90] = -1.0
+        rows.append(r)
+        rows.append(np.where(rng.random(n) < 0.5, -0.5, 0.5) + rng.normal(0, 1e-3, n))        # bimodal: MAD 0.5
+    saturated = exact = 0
+    for r in rows + [np.clip(rng.normal(0.0, 0.25, 240000), -1.0, 1.0), np.clip(rng.normal(0.0, 0.12, 240000), -1.0, 1.0)]:
+        c = torch.from_numpy(np.ascontiguousarray(r).reshape(1, -1)).to(engine.device)
+        thr, peaks, npeaks = engine.pick(c)
+        t_ref, med, mad = oracle.cfar_threshold(r)
+        assert float(thr[0]) == t_ref, (r.size, float(thr[0]), t_ref)
+        saturated += t_ref == 0.95; exact += t_ref < 0.95
+        pk, tot, fb = oracle.pick_peaks(r, t_ref)
+        k = int(npeaks[0]) & 0xFFFF                              # the count is not capped at the 32 peaks that are stored
+        assert k == tot and bool(int(npeaks[0]) >> 30) == fb, (r.size, k, tot)
+        assert list(peaks[0, :min(k, 32)].cpu().numpy()) == list(pk[:min(k, 32)])
+    assert saturated >= 12 and exact >= 12, (saturated, exact)
+    r = np.clip(rng.normal(0.0, 0.3, 5000), -1.0, 1.0); r[123] = np.nan                        # a NaN must not be "proven" anything
+    c = torch.from_numpy(r.reshape(1, -1)).to(engine.device)
+    thr_nan, _, _ = engine.pick(c)
+    engine_exact = float(thr_nan[0])
+    assert engine_exact != engine_exact or engine_exact <= 0.95
+
+
 def test_edge_records(engine, oracle):
     ba, tpl, taps, ntaps, _ = pack_tables()
     rng = np.random.default_rng(8)
