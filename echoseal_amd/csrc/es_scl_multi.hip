@@ -37,6 +37,10 @@ struct MCfg {
     static constexpr int GSLOT = N - (N >> GDEPTH);                // doubles per path slot in the slab (992 / 1008)
     static constexpr int ROW = 2 * (N >> (GDEPTH + 1)) + 4;        // LDS row: depths GDEPTH+1 .. RD-1 at [S, 2S); + 4 pad (bank spread between paths)
     static constexpr bool TBW_GLOBAL = (PP == 2);                  // trace-back windows in the slab instead of LDS (LDS budget: three blocks per CU)
+    // slot-storage loops: load pairs in flight in the g loops / next f operand pair requested ahead.  Measured (B = 65 536, L = 8): two lanes per
+    // path 2.32 -> 2.43 M frames/s with (2, prefetch); four lanes per path is fastest with neither (2.19 M; (2, -) 1.93 M: spills)
+    static constexpr int GBATCH = (PP == 2) ? 2 : 1;
+    static constexpr bool PREFETCH = (PP == 2);
 };
 constexpr int MWIN = KINFO / 32;                   // trace-back windows of 32 information bits
 constexpr int MWPB = 4;                            // waves per block
@@ -45,9 +49,6 @@ constexpr int MWPB = 4;                            // waves per block
 #endif
 #ifndef ES_MULTI_ILP
 #define ES_MULTI_ILP 1                             // independent f evaluations in flight per lane in the slot-storage loops
-#endif
-#ifndef ES_MULTI_PREFETCH
-#define ES_MULTI_PREFETCH 0                         /* next pair of parents loaded ahead: measured slower (1.51 M against 1.75 M frames/s) */
 #endif
 constexpr int MMINW = ES_MULTI_MINW;
 template <int PP> constexpr int mslab_doubles() { return MCfg<PP>::NP * MCfg<PP>::GSLOT + (MCfg<PP>::TBW_GLOBAL ? MWIN * MCfg<PP>::NP / 2 : 0); }   // per wave
@@ -237,46 +238,66 @@ __global__ __launch_bounds__(64 * MWPB, ((L <= 8 || PP == 2) ? MMINW : 1)) void 
                 const int jst = first ? FL : P;
                 const double* par_l = &W.alphaS[ps][2 * S];                    // (depth d-1 in the slab: region offset N - 4S; depth d: N - 2S)
                 double* dst_l = &W.alphaS[own][S];
-                auto load_pair = [&](int j, double& pa, double& pb) {
-                    if (d == 1) {
-                        if (a.is_f64) { pa = llr64[j]; pb = llr64[j + S]; }
-                        else { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }
-                    } else if (d - 1 <= MGDEPTH) { pa = *gaddr(N - 4 * S, ps, j); pb = *gaddr(N - 4 * S, ps, j + S); }
-                    else { pa = par_l[j]; pb = par_l[j + S]; }
-                };
-                auto store_out = [&](int j, double v) { if (d <= MGDEPTH) *gaddr(N - 2 * S, own, j) = v; else dst_l[j] = v; };
-                if (is_g) {
-                    for (int j = q; j < S; j += P) {
-                        double pa, pb; load_pair(j, pa, pb);
-                        const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + j) >> 5];
-                        store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
-                    }
-                } else {
-                    int j = j0;
+                // Loaders and stores are chosen OUTSIDE the element loops (channel LLRs / slab / LDS): with the choice inside, control flow sits
+                // between a load and its use and the compiler waits for everything outstanding after every load (as in es_scl_wide.hip).
+                auto run_level = [&](auto load_pair, auto store_out) {
+                    if (is_g) {
+                        int j = q;
+                        if constexpr (C::GBATCH > 1) {
+                            for (; j + (C::GBATCH - 1) * P < S; j += C::GBATCH * P) {      // (g is an add: the loop is load latency) independent pairs in flight
+                                double xa[C::GBATCH], xb[C::GBATCH];
+                                #pragma unroll
+                                for (int v = 0; v < C::GBATCH; ++v) load_pair(j + v * P, xa[v], xb[v]);
+                                #pragma unroll
+                                for (int v = 0; v < C::GBATCH; ++v) {
+                                    const int jj = j + v * P;
+                                    const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + jj) >> 5];
+                                    store_out(jj, es_polar_g(xa[v], xb[v], (wbits >> ((S + jj) & 31)) & 1u));
+                                }
+                            }
+                        }
+                        for (; j < S; j += P) {
+                            double pa, pb; load_pair(j, pa, pb);
+                            const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + j) >> 5];
+                            store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
+                        }
+                    } else {
+                        int j = j0;
 #if ES_MULTI_ILP == 2
-                    for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
-                        double a0, c0, a1, c1; load_pair(j, a0, c0); load_pair(j + jst, a1, c1);
-                        const double o0 = es_polar_f(a0, c0, tab);
-                        const double o1 = es_polar_f(a1, c1, tab);
-                        store_out(j, o0); store_out(j + jst, o1);
-                    }
+                        for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
+                            double a0, c0, a1, c1; load_pair(j, a0, c0); load_pair(j + jst, a1, c1);
+                            const double o0 = es_polar_f(a0, c0, tab);
+                            const double o1 = es_polar_f(a1, c1, tab);
+                            store_out(j, o0); store_out(j + jst, o1);
+                        }
 #endif
-                    // one f (= two interleaved softplus chains) in flight per lane: the other waves of the SIMD hide the rest
-#if ES_MULTI_PREFETCH
-                    // ... and the NEXT pair of parents already on its way from the slab (two loads, four registers)
-                    if (j < S) {
-                        double pa, pb; load_pair(j, pa, pb);
-                        for (; j < S; j += jst) {
-                            double na = 0.0, nb = 0.0;
-                            if (j + jst < S) load_pair(j + jst, na, nb);
-                            store_out(j, es_polar_f(pa, pb, tab));
-                            pa = na; pb = nb;
+                        // one f (= two interleaved softplus chains) in flight per lane: the other waves of the SIMD hide the rest
+                        if constexpr (C::PREFETCH) {
+                            // ... and the NEXT pair of parents already on its way (past the end: this lane's last element again)
+                            if (j < S) {
+                                double pa, pb; load_pair(j, pa, pb);
+                                for (; j < S; j += jst) {
+                                    double na, nb;
+                                    load_pair(j + jst < S ? j + jst : j, na, nb);
+                                    store_out(j, es_polar_f(pa, pb, tab));
+                                    pa = na; pb = nb;
+                                }
+                            }
+                        } else {
+                            for (; j < S; j += jst) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
                         }
                     }
-#else
-                    for (; j < S; j += jst) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
-#endif
-                }
+                };
+                auto st_slab = [&](int j, double v) { *gaddr(N - 2 * S, own, j) = v; };
+                auto st_lds = [&](int j, double v) { dst_l[j] = v; };
+                auto ld_slab = [&](int j, double& pa, double& pb) { pa = *gaddr(N - 4 * S, ps, j); pb = *gaddr(N - 4 * S, ps, j + S); };
+                auto ld_lds = [&](int j, double& pa, double& pb) { pa = par_l[j]; pb = par_l[j + S]; };
+                if (d == 1) {                                                  // the channel LLRs (depth 1 always lives in the slab)
+                    if (a.is_f64) run_level([&](int j, double& pa, double& pb) { pa = llr64[j]; pb = llr64[j + S]; }, st_slab);
+                    else run_level([&](int j, double& pa, double& pb) { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }, st_slab);
+                } else if (d <= MGDEPTH) run_level(ld_slab, st_slab);
+                else if (d - 1 <= MGDEPTH) run_level(ld_slab, st_lds);
+                else run_level(ld_lds, st_lds);
                 if (d <= MGDEPTH) wave_fence_global(); else wave_fence_lds();
                 ptrA = ptr_set(ptrA, d, own);
             }
