@@ -215,9 +215,9 @@ int es_pick_exact_batch(es_ctx* ctx, const float* corr32_dev, const double* y_de
     hipStream_t st = (hipStream_t)stream;
     int rc = es_launch_pick_exact(ctx, corr32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, st);
     if (rc) return rc;
-    rc = es_launch_xcorr_flagged(ctx, y_dev, B, T, band_dev, ctx->d_ws_corr, flags_dev, nullptr, st);
+    rc = es_launch_xcorr_flagged(ctx, y_dev, B, T, band_dev, ctx->d_ws_corr, flags_dev, st);
     if (rc) return rc;
-    return es_launch_pick_flagged(ctx, ctx->d_ws_corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, flags_dev, nullptr, st);
+    return es_launch_pick_flagged(ctx, ctx->d_ws_corr, B, n_lags, thr_dev, peaks_dev, npeaks_dev, flags_dev, st);
 }
 
 int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, int64_t B, int T,
@@ -233,7 +233,7 @@ int es_sync_fused_batch(es_ctx* ctx, const float* y32_dev, const double* y_dev, 
     DeviceGuard g(ctx->device);
     /* one launch: records the screen cannot settle are settled by the same wave from float64 re-evaluations (flags_dev
        then carries the reason code, for information) */
-    return es_launch_sync_fused(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, nullptr, (hipStream_t)stream);
+    return es_launch_sync_fused(ctx, y32_dev, y_dev, B, T, band_dev, thr_dev, peaks_dev, npeaks_dev, flags_dev, (hipStream_t)stream);
 }
 
 int es_front_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, int T, const uint8_t* band_dev,

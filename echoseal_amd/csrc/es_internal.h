@@ -96,12 +96,12 @@ int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uin
 int es_launch_pick_exact(es_ctx* ctx, const float* corr32, const double* y, int64_t B, int T, const uint8_t* band,
                          double* thr, int32_t* peaks, int32_t* npeaks, uint8_t* flags, hipStream_t st);
 int es_launch_sync_fused(es_ctx* ctx, const float* y32, const double* y, int64_t B, int T, const uint8_t* band, double* thr,
-                         int32_t* peaks, int32_t* npeaks, uint8_t* flags, int* nflag, hipStream_t st);
-/* redo of flagged records by the float64 kernels; nflag (nullable): device counter -- when it reads 0 every block leaves at once */
+                         int32_t* peaks, int32_t* npeaks, uint8_t* flags, hipStream_t st);
+/* redo of flagged records by the float64 kernels */
 int es_launch_xcorr_flagged(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
-                            const uint8_t* flags, const int* nflag, hipStream_t st);
+                            const uint8_t* flags, hipStream_t st);
 int es_launch_pick_flagged(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
-                           int32_t* npeaks, const uint8_t* flags, const int* nflag, hipStream_t st);
+                           int32_t* npeaks, const uint8_t* flags, hipStream_t st);
 int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
                     hipStream_t st);
 int es_launch_pick(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,

@@ -443,9 +443,8 @@ constexpr int XC_WAVES = 4;
 
 __global__ __launch_bounds__(64 * XC_WAVES) void es_xcorr_kernel(const double* __restrict__ y, long long B,
         int T, const uint8_t* __restrict__ band, const es_band_tables* __restrict__ tabs,
-        double* __restrict__ corr, const uint8_t* __restrict__ only_flagged, const int* __restrict__ nflag)
+        double* __restrict__ corr, const uint8_t* __restrict__ only_flagged)
 {
-    if (nflag && *nflag == 0) return;                          // redo pass with nothing flagged: leave at once
     __shared__ double s_buf[XC_WAVES][XC_NS + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double* s = s_buf[wv];
@@ -662,9 +661,8 @@ __device__ bool block_threshold_saturates(const double* v, int n, uint32_t* s_hi
 template <bool IN_LDS, int NT>
 __global__ __launch_bounds__(NT) void es_pick_kernel(const double* __restrict__ corr, long long B,
         int n, double* __restrict__ thr_out, int32_t* __restrict__ peaks, int32_t* __restrict__ npeaks,
-        const uint8_t* __restrict__ only_flagged, const int* __restrict__ nflag)
+        const uint8_t* __restrict__ only_flagged)
 {
-    if (nflag && *nflag == 0) return;                          // redo pass with nothing flagged: leave at once
     __shared__ double s_row[IN_LDS ? PK_LDS_N : 1];
     __shared__ uint32_t s_hist[256];
     __shared__ uint64_t s_pref;
@@ -817,19 +815,19 @@ int es_launch_bpf(es_ctx* ctx, const void* frames, int dtype, int64_t B, int T, 
 int es_launch_xcorr(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
                     hipStream_t st)
 {
-    return es_launch_xcorr_flagged(ctx, y, B, T, band, corr, nullptr, nullptr, st);
+    return es_launch_xcorr_flagged(ctx, y, B, T, band, corr, nullptr, st);
 }
 
 int es_launch_xcorr_flagged(es_ctx* ctx, const double* y, int64_t B, int T, const uint8_t* band, double* corr,
-                            const uint8_t* flags, const int* nflag, hipStream_t st)
+                            const uint8_t* flags, hipStream_t st)
 {
     const int n_lags = T - (ES_PRE_L - 1);
     const long long nseg = (n_lags + XC_SEG - 1) / XC_SEG;
     long long blocks = (B * nseg + XC_WAVES - 1) / XC_WAVES;
-    const long long cap = (long long)ctx->num_cu * (nflag ? 2 : 16);          // a redo pass rarely has anything to do
+    const long long cap = (long long)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(es_xcorr_kernel, dim3((unsigned)blocks), dim3(64 * XC_WAVES), 0, st, y, (long long)B,
-                       T, band, ctx->d_tables, corr, flags, nflag);
+                       T, band, ctx->d_tables, corr, flags);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
@@ -837,21 +835,21 @@ int es_launch_xcorr_flagged(es_ctx* ctx, const double* y, int64_t B, int T, cons
 int es_launch_pick(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
                    int32_t* npeaks, hipStream_t st)
 {
-    return es_launch_pick_flagged(ctx, corr, B, n_lags, thr, peaks, npeaks, nullptr, nullptr, st);
+    return es_launch_pick_flagged(ctx, corr, B, n_lags, thr, peaks, npeaks, nullptr, st);
 }
 
 int es_launch_pick_flagged(es_ctx* ctx, const double* corr, int64_t B, int n_lags, double* thr, int32_t* peaks,
-                           int32_t* npeaks, const uint8_t* flags, const int* nflag, hipStream_t st)
+                           int32_t* npeaks, const uint8_t* flags, hipStream_t st)
 {
     long long blocks = B;
-    const long long cap = (long long)ctx->num_cu * (nflag ? 2 : 16);
+    const long long cap = (long long)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
     if (n_lags <= PK_LDS_N)
         hipLaunchKernelGGL((es_pick_kernel<true, PK_THREADS>), dim3((unsigned)blocks), dim3(PK_THREADS), 0, st, corr,
-                           (long long)B, n_lags, thr, peaks, npeaks, flags, nflag);
+                           (long long)B, n_lags, thr, peaks, npeaks, flags);
     else                                              // long rows (recordings): one block per row, so make it a big one
         hipLaunchKernelGGL((es_pick_kernel<false, 1024>), dim3((unsigned)blocks), dim3(1024), 0, st, corr,
-                           (long long)B, n_lags, thr, peaks, npeaks, flags, nflag);
+                           (long long)B, n_lags, thr, peaks, npeaks, flags);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }

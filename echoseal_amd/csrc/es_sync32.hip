@@ -54,7 +54,6 @@ constexpr int XF_MIN_WAVES = 3;                     // <= 168 VGPRs: a fused-syn
 struct FusedArgs {
     const double* y64;                              // [B][T] float64 band-passed records (exact re-evaluations)
     double* thr; int32_t* peaks; int32_t* npeaks; uint8_t* flags;
-    int* nflag;                                     // device counter of flagged records (nullable)
 };
 struct PwFixed;
 __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, const double* tpl, long long rec, int lane,
@@ -561,7 +560,7 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
     const int min_distance = ES_FRAME_LEN / 2;
     // a record the screen cannot settle: reason code to flags (informational), then the exact row by this same wave
     auto flag_out = [&](int code) {
-        if (lane == 0) { fo.flags[rec] = (uint8_t)code; if (fo.nflag) atomicAdd(fo.nflag, 1); }
+        if (lane == 0) fo.flags[rec] = (uint8_t)code;
         wave_fence_lds();
         sync_exact_row(S, n, yr, tpl, rec, lane, fo);
     };
@@ -925,7 +924,7 @@ int es_launch_pick_exact(es_ctx* ctx, const float* corr32, const double* y, int6
 }
 
 int es_launch_sync_fused(es_ctx* ctx, const float* y32, const double* y, int64_t B, int T, const uint8_t* band, double* thr,
-                         int32_t* peaks, int32_t* npeaks, uint8_t* flags, int* nflag, hipStream_t st)
+                         int32_t* peaks, int32_t* npeaks, uint8_t* flags, hipStream_t st)
 {
     const int n_lags = T - (ES_PRE_L - 1);
     if (n_lags > PX_MAXN) { ctx->err = "es_sync_fused_batch: more than 4096 lags; use the float64 path"; return ES_EINVAL; }
@@ -937,7 +936,7 @@ int es_launch_sync_fused(es_ctx* ctx, const float* y32, const double* y, int64_t
     long long blocks = (B + XF_WAVES - 1) / XF_WAVES;
     const long long cap = (long long)ctx->num_cu * 32;
     if (blocks > cap) blocks = cap;
-    const FusedArgs fo{y, thr, peaks, npeaks, flags, nflag};
+    const FusedArgs fo{y, thr, peaks, npeaks, flags};
     if (win2k)
         hipLaunchKernelGGL((es_xcorr32_kernel<XC_R_WINDOW, XC_T_WINDOW, true>), dim3((unsigned)blocks), dim3(64 * XF_WAVES), lds, st, y32,
                            (long long)B, T, band, ctx->d_tables, (float*)nullptr, fo);
