@@ -136,6 +136,13 @@ def test_verify_batch_equals_sequential_verify(engine):
     assert b.verify_batch(clips, 48_000) == seq
     assert a._trace == b._trace and a._hdr_trace == b._hdr_trace and a.session_nonce == b.session_nonce
     assert len(a._trace) > 20
+    # the same with the candidates decoded in many small batches (the cap on pairs per decode launch forces the lazy, walk-ordered
+    # batching through every branch: a band split over launches, batches that span bands and clips, bands decoded but never walked)
+    for cap in (2, 7, 50):
+        c = WatermarkDetector(KEY, list_size=2, engine=engine); c._trace = []; c._hdr_trace = []
+        c._pair_cap = lambda cap=cap: cap
+        assert c.verify_batch(clips, 48_000) == seq, cap
+        assert a._trace == c._trace and a._hdr_trace == c._hdr_trace and a.session_nonce == c.session_nonce, cap
 
 
 @pytest.mark.gpu
