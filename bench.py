@@ -232,8 +232,8 @@ def run_rank(a) -> None:
     L = a.list_size
     eng = RxEngine(local, list_size_max=max(16, L))
     tx = WatermarkEmbedder(KEY)
-    # Eight hardware queues: every pipeline of this process runs on the SAME seven streams (four front-end streams at high priority,
-    # two list-decoder / big-launch streams, one spare for the seven-lane leg)
+    # Eight hardware queues: every pipeline of this process runs on the SAME eight streams (four made at high priority for the grouped
+    # pipeline's front ends, four further ones: list-decoder streams of the grouped pipeline, lanes of the 65 536-record launches)
     front_streams = pipeline_streams(dev, a.front_lanes, priority=-1)
     back_streams = pipeline_streams(dev, max(a.scl_streams, min(a.big_lanes, 8 - a.front_lanes)))
     big_streams = (back_streams + front_streams)[:a.big_lanes]                # the lanes of the 65 536-record launches
