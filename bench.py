@@ -24,6 +24,8 @@ Further driver-timed legs in the same JSON line (`legs`), each bracketed by barr
   c2_single one 1 024-frame batch alone, submission to completion (latency, not throughput).
   c3_unfused the headline's pass with the correlation row going through HBM (es_xcorr32_batch -> es_pick_exact_batch): identical
             results; `roofline` is the stand-alone correlation kernel INSIDE this leg (HIP events on its launch stream).
+  c3_pcie   the headline with every step's samples copied from pinned host memory over PCIe (copy stream, overlapped): the rate when the
+            boundary hands over host buffers.  Reported beside the headline, never as `value`.
   c4        BASELINE config 4, strong scaling: 2^20 frames in total, ctr 0 .. 2^20-1, sharded contiguously over the N ranks; rank 0
             derives the whole schedule (153 B per counter = 160 MB) and broadcasts it; a checksum over (frame index, payload, ok,
             sync offset) summed over ranks is the same number at every N.
@@ -75,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=65536, help="C3 windows per GPU per step (BASELINE config 3 = 65 536)")
     ap.add_argument("--list-size", type=int, default=8)
-    ap.add_argument("--legs", default="auto", help="comma list of c2,c2_lanes,c3_unfused,c4,c5 (auto: all at N = 1, c2 + c4 at N > 1; none: headline only)")
+    ap.add_argument("--legs", default="auto", help="comma list of c2,c2_lanes,c3_unfused,c3_pcie,c4,c5 (auto: all at N = 1, c2 + c4 at N > 1; none: headline only)")
     ap.add_argument("--big-lanes", type=int, default=4, help="pipeline lanes of the headline and of the c4 leg (launches of 65 536 records): up to 8")
     ap.add_argument("--frames", type=int, default=1024, help="frame records per batch of the c2 legs (C2 = 1024)")
     ap.add_argument("--c2-steps", type=int, default=480)
@@ -228,7 +230,7 @@ def run_rank(a) -> None:
     from echoseal_amd.engine import DecodePipeline, RxEngine, pipeline_streams
     from echoseal_amd import workloads as WL
 
-    legs = {"auto": ["c2", "c2_lanes", "c3_unfused", "c4", "c5"] if world == 1 else ["c2", "c4"], "none": []}.get(a.legs, a.legs.split(","))
+    legs = {"auto": ["c2", "c2_lanes", "c3_unfused", "c3_pcie", "c4", "c5"] if world == 1 else ["c2", "c4"], "none": []}.get(a.legs, a.legs.split(","))
     L = a.list_size
     eng = RxEngine(local, list_size_max=max(16, L))
     tx = WatermarkEmbedder(KEY)
@@ -361,6 +363,44 @@ def run_rank(a) -> None:
                                   "value": world * Bw * nu / dtu, "unit": "frames/s", "scaling": "weak", "steps": nu, "ms_per_step": 1e3 * dtu / nu,
                                   "stage_ms": stage_u, "results_identical_to_the_headline": same}
         del pk2, npk2, payload2, ok2
+    # ============================================================ leg c3_pcie: the headline with every step's samples coming over PCIe
+    if "c3_pcie" in legs:
+        # the boundary may hand over HOST buffers: each step's 65 536 windows (0.5 GB) are copied from pinned host memory on a copy
+        # stream into one of `big_lanes` + 1 device buffers while earlier steps decode; the lane waits for its copy.  Never `value`.
+        nbuf = a.big_lanes + 1
+        host = torch.empty(win.shape, dtype=win.dtype, pin_memory=True)
+        host.copy_(win)
+        copy_st = torch.cuda.Stream(dev)
+        bufs = [torch.empty_like(win) for _ in range(nbuf)]
+        free_ev = [None] * nbuf                                   # the step that last read the buffer
+
+        def pcie_step(k):
+            b = k % nbuf
+            with torch.cuda.stream(copy_st):
+                if free_ev[b] is not None:
+                    copy_st.wait_event(free_ev[b])
+                bufs[b].copy_(host, non_blocking=True)
+                ready = torch.cuda.Event(); ready.record()
+            torch.cuda.current_stream(dev).wait_event(ready)       # (submit makes the lane wait for the caller's stream)
+            sy, _llr, scl, done = pipe3.submit(bufs[b], band3, pn3, start="peak", select=True)
+            free_ev[b] = done
+            return sy, scl
+        for k in range(nbuf):
+            pcie_step(k)
+        torch.cuda.synchronize()
+        npc = max(8, a.steps // 2)
+        barrier()
+        tp = time.perf_counter()
+        for k in range(npc):
+            syp, sclp = pcie_step(k)
+        barrier()
+        dtp = max_over_ranks(time.perf_counter() - tp)
+        same_p = bool(torch.equal(syp.peaks, pk) and torch.equal(sclp.selected[0], payload3))
+        out_legs["c3_pcie"] = {"workload": "the headline with each step's 0.5 GB of samples copied from pinned host memory (copy stream, "
+                                           f"{nbuf} device buffers) instead of resident in HBM",
+                               "value": world * Bw * npc / dtp, "unit": "frames/s", "scaling": "weak", "steps": npc, "ms_per_step": 1e3 * dtp / npc,
+                               "host_to_device_GBps_needed": win.numel() * 4 * npc / dtp / 1e9, "results_identical_to_the_headline": same_p}
+        del host, bufs, syp, sclp
     del pk_s, npk_s, payload_s, ok_s, sy3, scl3, payload3, ok3, pk, npk
     win_h = band_h = pn_h = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
