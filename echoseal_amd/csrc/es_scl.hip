@@ -195,30 +195,49 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
                 const int jst = first ? 64 : P;
                 double* dst_g = scr + own * GSLOT + (N - 2 * S);
                 double* dst_l = &W.alphaS[own][S];
-                auto load_pair = [&](int j, double& pa, double& pb) {
-                    if (d == 1) {
-                        if (a.is_f64) { pa = llr64[j]; pb = llr64[j + S]; }
-                        else { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }
-                    } else if (d - 1 <= GDEPTH) { pa = par_g[j]; pb = par_g[j + S]; }
-                    else { pa = par_l[j]; pb = par_l[j + S]; }
+                // Loaders and stores are chosen OUTSIDE the element loops (channel LLRs / scratch / LDS): with the choice inside, control flow
+                // sits between a load and its use and the compiler waits for everything outstanding after every load -- the g loops of the
+                // top depths (pure load latency at one wave per SIMD) ran one memory round trip per element pair.
+                auto run_level = [&](auto load_pair, auto store_out) {
+                    if (is_g) {
+                        int j = q;
+                        for (; j + 3 * P < S; j += 4 * P) {                       // four independent pairs in flight
+                            double xa[4], xb[4];
+                            #pragma unroll
+                            for (int v = 0; v < 4; ++v) load_pair(j + v * P, xa[v], xb[v]);
+                            #pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int jj = j + v * P;
+                                const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + jj) >> 5];
+                                store_out(jj, es_polar_g(xa[v], xb[v], (wbits >> ((S + jj) & 31)) & 1u));
+                            }
+                        }
+                        for (; j < S; j += P) {
+                            double pa, pb; load_pair(j, pa, pb);
+                            const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + j) >> 5];
+                            store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
+                        }
+                    } else {
+                        int j = j0;
+                        for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
+                            double a0, c0, a1, c1; load_pair(j, a0, c0); load_pair(j + jst, a1, c1);
+                            const double o0 = es_polar_f(a0, c0, tab);
+                            const double o1 = es_polar_f(a1, c1, tab);
+                            store_out(j, o0); store_out(j + jst, o1);
+                        }
+                        if (j < S) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
+                    }
                 };
-                auto store_out = [&](int j, double v) { if (d <= GDEPTH) dst_g[j] = v; else dst_l[j] = v; };
-                if (is_g) {
-                    for (int j = q; j < S; j += P) {
-                        double pa, pb; load_pair(j, pa, pb);
-                        const uint32_t wbits = (S <= 16) ? b0 : W.betaL[bs][(S + j) >> 5];
-                        store_out(j, es_polar_g(pa, pb, (wbits >> ((S + j) & 31)) & 1u));
-                    }
-                } else {
-                    int j = j0;
-                    for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
-                        double a0, b0, a1, b1; load_pair(j, a0, b0); load_pair(j + jst, a1, b1);
-                        const double o0 = es_polar_f(a0, b0, tab);
-                        const double o1 = es_polar_f(a1, b1, tab);
-                        store_out(j, o0); store_out(j + jst, o1);
-                    }
-                    if (j < S) { double pa, pb; load_pair(j, pa, pb); store_out(j, es_polar_f(pa, pb, tab)); }
-                }
+                auto st_g = [&](int j, double v) { dst_g[j] = v; };
+                auto st_l = [&](int j, double v) { dst_l[j] = v; };
+                auto ld_g = [&](int j, double& pa, double& pb) { pa = par_g[j]; pb = par_g[j + S]; };
+                auto ld_l = [&](int j, double& pa, double& pb) { pa = par_l[j]; pb = par_l[j + S]; };
+                if (d == 1) {                                                  // the channel LLRs (depth 1 lives in the scratch slab)
+                    if (a.is_f64) run_level([&](int j, double& pa, double& pb) { pa = llr64[j]; pb = llr64[j + S]; }, st_g);
+                    else run_level([&](int j, double& pa, double& pb) { pa = (double)llr32[j]; pb = (double)llr32[j + S]; }, st_g);
+                } else if (d <= GDEPTH) run_level(ld_g, st_g);
+                else if (d - 1 <= GDEPTH) run_level(ld_g, st_l);
+                else run_level(ld_l, st_l);
                 if (d <= GDEPTH) wave_fence_global(); else wave_fence_lds();
                 ptrA = ptr_set(ptrA, d, own);
 #ifdef ES_SCL_STAMPS
