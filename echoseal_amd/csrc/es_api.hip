@@ -363,23 +363,28 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     int lp = 1; while (lp < list_size) lp <<= 1;              // the kernels are built for powers of two; any size runs on the next one
-    // One lane per path, 64/L frames per wave (es_scl_wide.hip): fewest instructions per frame (every lane busy at every tree depth) but
-    // a wave carries 64/L frames through the whole decode, so by itself it needs a batch that gives every SIMD three such waves (a pipeline that keeps several launches in flight forces it earlier): measured at
-    // L = 8, 2.0 against 1.8 M frames/s at 16 384 frames, 2.7 against 2.2 M at 73 728, and 0.2 against 0.46 M at 1 000.  Chosen by
-    // batch size when the context has that kernel's slab (list_size_max > 32, or es_set_option "scl_lane_slab").
-    const bool lane_auto = ctx->scl_lanes == 0 && ctx->scl_multi < 0 && ctx->d_wide_scratch && lp >= 2 && (long long)B * lp / 64 >= 3LL * ctx->num_cu * 4;
+    // Which mapping?  Measured on one MI355X (tools/mapping_sweep.py, round 3; milliseconds per launch at L = 8):
+    //      B        one frame per wave   4 lanes per path   2 lanes per path   1 lane per path
+    //    2 048            1.68                 2.02               2.89              3.46
+    //    4 096            3.29                 2.58               3.01              3.72
+    //    8 192            6.54                 4.77               4.09              4.03
+    //   16 384           13.13                 8.19               8.14              6.46
+    //   65 536           52.39                30.13              27.04             21.73
+    // One lane per path (es_scl_wide.hip: fewest instructions per frame, but a wave carries 64/L frames through the whole decode) wins
+    // once the batch yields about one such wave per SIMD -- earlier for long lists, never for L = 1; it needs that kernel's slab
+    // (list_size_max > 32, or es_set_option "scl_lane_slab").
+    const long long wide_waves = (long long)B * lp / 64;
+    const long long wide_min = (lp == 2 ? 3072LL : lp <= 8 ? 1024LL : lp == 16 ? 768LL : 256LL) * ctx->num_cu / 256;
+    const bool lane_auto = ctx->scl_lanes == 0 && ctx->scl_multi < 0 && ctx->d_wide_scratch && lp >= 2 && wide_waves >= wide_min;
     if ((ctx->scl_lanes == 1 && ctx->scl_multi != 0) || lane_auto)
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     if (lp <= 32) {
-        // several frames per wave (es_scl_multi.hip) once the batch yields enough such waves (16/L frames each).  One
-        // frame per wave wastes more lanes the shorter the list is, so the break-even moves down with L: measured
-        // at L = 8 it is two waves per SIMD (B = 4 096), at L = 1 a quarter of a wave per SIMD.
-        const long long waves = (B * lp + 15) / 16;
-        // L = 16 and 32 map to one frame per wave on either kernel (16 paths x 4 lanes, 32 x 2); the multi-frame kernel's smaller
-        // footprint (three waves per SIMD, non-persistent blocks) wins as soon as the batch exceeds one wave per SIMD:
-        // measured 2.1x at L = 16 and 4.1x at L = 32 for 16 384 frames, equal below 1 024 / 512 frames.
-        const bool fits = lp <= 8 ? waves >= (long long)ctx->num_cu * lp : B >= (lp == 16 ? 4LL : 2LL) * ctx->num_cu + (lp == 32);
+        // Several frames per wave (es_scl_multi.hip, 16/L frames per wave at four lanes per path) against one frame per wave: the
+        // break-even is ~3 000 frames for L <= 8 (1.5 of the former's waves per SIMD at L = 8), ~1 500 frames for L = 16, ~512 for L = 32
+        // (where both map one frame to a wave and the multi-frame kernel's smaller footprint -- three waves per SIMD, non-persistent
+        // blocks -- wins as soon as the batch exceeds one wave per SIMD).
+        const bool fits = lp <= 8 ? B >= 12LL * ctx->num_cu : B >= (lp == 16 ? 6LL : 2LL) * ctx->num_cu + (lp == 32);
         const bool multi = ctx->scl_multi == 1 || (ctx->scl_multi < 0 && fits);
         if (multi)
             return es_launch_scl_multi(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,

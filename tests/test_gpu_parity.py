@@ -573,6 +573,30 @@ def test_front_batch_equals_separate_calls(engine):
         engine.front(f.double(), b, p)
 
 
+def test_front_end_context_and_stream_budget(engine):
+    """es_create(device, 0): a front-end context runs everything but the list decoder and says so; pipelines warn when more streams are
+    alive than the HIP runtime has hardware queues."""
+    import warnings
+    from echoseal_amd._native import NativeError
+    from echoseal_amd.engine import RxEngine, DecodePipeline, hw_queue_budget, pipeline_streams
+    fe = RxEngine(engine.device, list_size_max=0)
+    frames, band, pn = _workload(64, noise=0.1, seed=3)
+    f, b, p = _dev(engine, frames, band, pn)
+    y, thr, peaks, npeaks, flags, llr = fe.front(f, b, p)
+    y2, thr2, peaks2, npeaks2, flags2, llr2 = engine.front(f, b, p)
+    assert torch.equal(y, y2) and torch.equal(peaks, peaks2) and torch.equal(llr, llr2)
+    with pytest.raises(NativeError, match="front-end context"):
+        fe.scl(llr, list_size=8)
+    assert hw_queue_budget() >= 4
+    keep = []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(hw_queue_budget() // 2 + 2):
+            keep.append(DecodePipeline(engine, list_size=4, lanes=2))
+        assert any("hardware queues" in str(x.message) for x in w)
+    del keep
+
+
 def test_pipeline_on_given_streams(engine):
     """DecodePipeline(streams=...) runs its lanes on existing HIP streams (a process should not keep more than eight alive):
     same rows as decode_batch; a wrong number of streams is refused."""

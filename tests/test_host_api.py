@@ -141,3 +141,19 @@ def test_wav_ingest_round_trip(tmp_path):
     y, fs = read_wav(p)
     assert fs == 44_100 and np.max(np.abs(y.astype(np.float64) / 32768.0 - f)) <= 0.5 / 32768 + 1e-12
     assert np.array_equal((y.astype(np.float64) / 32768.0).astype(np.float32), y.astype(np.float32) / np.float32(32768.0))
+
+
+def test_undecoded_records_raise_not_pass_silently():
+    """ncand < 0 (a list-decoder block that found no scratch-slab slot) must surface as an exception wherever results are consumed."""
+    import torch
+    from echoseal_amd._native import NativeError
+    from echoseal_amd.engine import SclResult, select_payload
+    z = torch.zeros
+    res = SclResult(z((3, 55), dtype=torch.uint8), z(3, dtype=torch.uint8), z((3, 8, 55), dtype=torch.uint8), z((3, 8), dtype=torch.float64),
+                    z((3, 8), dtype=torch.uint8), torch.tensor([8, -1, 0], dtype=torch.int32))
+    with pytest.raises(NativeError, match="not decoded"):
+        res.check()
+    with pytest.raises(NativeError, match="not decoded"):
+        select_payload(res, 1)
+    res.ncand[1] = 8
+    assert res.check() is res
