@@ -30,6 +30,7 @@ SIGNATURES = {
     "es_destroy": (None, [c_void_p]),
     "es_last_error": (c_char_p, [c_void_p]),
     "es_abi_version": (c_int, []),
+    "es_info_bytes": (c_int, [c_void_p]),
     "es_set_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "es_bpf_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "es_bpf2_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -48,6 +48,8 @@ extern "C" {
 
 int es_abi_version(void) { return 1; }
 
+int es_info_bytes(const es_ctx* ctx) { return (ctx && ctx->n_info >= 16) ? ctx->n_info / 8 - 1 : ES_INFO_BYTES; }
+
 const char* es_last_error(const es_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 es_ctx* es_create(int device, int list_size_max)
@@ -145,7 +147,10 @@ int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float*
         if (frozen[i]) ctx->frozen.w[i >> 5] |= (1u << (i & 31));
         else dpos[n++] = (uint16_t)i;
     }
-    if (n != ES_POLAR_K) return fail(ctx, ES_EINVAL, "es_set_tables: frozen mask must leave exactly 448 information positions");
+    // 448 is the reference's own code (rtwm/polar_fast.py:8-9); its PolarCode class takes any K (rtwm/fastpolar.py:209-234), and so does
+    // es_scl_batch for whole bytes of data around the CRC-8.  (K = 1024 has no frozen position at all and is not served.)
+    if (n < 16 || n > ES_POLAR_N - 8 || n % 8)
+        return fail(ctx, ES_EINVAL, "es_set_tables: the frozen mask must leave K information positions with 16 <= K <= 1016 and K % 8 == 0 (448 for every entry point but es_scl_batch)");
     ctx->n_info = n;
     DeviceGuard g(ctx->device);
     ES_HIP_CHECK(ctx, hipMemcpy(ctx->d_tables, &h, sizeof h, hipMemcpyHostToDevice));
@@ -153,6 +158,11 @@ int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float*
     ctx->tables_ready = true;
     return ES_OK;
 }
+
+#define ES_REQUIRE_DEFAULT_CODE(ctx, who)                                                  \
+    do {                                                                                   \
+        if ((ctx)->n_info != ES_POLAR_K) return fail((ctx), ES_EINVAL, who ": this entry point serves the reference's own code only (448 information positions, 55-byte payloads)"); \
+    } while (0)
 
 #define ES_REQUIRE_READY(ctx)                                                              \
     do {                                                                                   \
@@ -359,7 +369,9 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     if (!llr_dev || !hard_info_dev || !hard_ok_dev || !cand_info_dev || !cand_metric_dev || !cand_ok_dev || !ncand_dev)
         return fail(ctx, ES_EINVAL, "es_scl_batch: null pointer");
     DeviceGuard g(ctx->device);
-    if (list_size > 32)
+    if (ctx->n_info != ES_POLAR_K && !ctx->d_wide_scratch)
+        return fail(ctx, ES_EINVAL, "es_scl_batch: a code other than K = 448 runs on the lane-per-path kernel only, and this context has no scratch for it (list_size_max <= 32 and scl_lanes 1 never requested before es_reserve)");
+    if (list_size > 32 || ctx->n_info != ES_POLAR_K)
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
                                   cand_info_dev, cand_metric_dev, cand_ok_dev, ncand_dev, (hipStream_t)stream);
     int lp = 1; while (lp < list_size) lp <<= 1;              // the kernels are built for powers of two; any size runs on the next one
@@ -469,6 +481,7 @@ int es_set_option(es_ctx* ctx, const char* name, int value)
 int es_polar_encode_batch(es_ctx* ctx, const uint8_t* info_dev, int64_t B, uint8_t* code_dev, void* stream)
 {
     ES_REQUIRE_READY(ctx);
+    ES_REQUIRE_DEFAULT_CODE(ctx, "es_polar_encode_batch");
     if (B < 0) return fail(ctx, ES_EINVAL, "es_polar_encode_batch: negative batch");
     if (B == 0) return ES_OK;
     if (!info_dev || !code_dev) return fail(ctx, ES_EINVAL, "es_polar_encode_batch: null pointer");
@@ -514,6 +527,7 @@ int es_select_batch(es_ctx* ctx, const uint8_t* key32_host, const uint32_t* ctr_
                     uint8_t* payload_dev, int8_t* ok_dev, int32_t* which_dev, void* stream)
 {
     ES_REQUIRE_READY(ctx);
+    ES_REQUIRE_DEFAULT_CODE(ctx, "es_select_batch");
     if (B < 0 || L < 1) return fail(ctx, ES_EINVAL, "es_select_batch: negative batch or list size < 1");
     if (B == 0) return ES_OK;
     if (!hard_info_dev || !hard_ok_dev || !cand_info_dev || !cand_metric_dev || !cand_ok_dev || !ncand_dev ||

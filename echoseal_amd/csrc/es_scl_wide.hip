@@ -71,12 +71,14 @@ struct WideArgs {
     int skip_if_hard_ok;
     int lsz;                                  // the caller's list size (<= L)
     unsigned* slot_bits; int n_slots, slot_words;   // bitmap of slab slots (one per resident block), as in es_scl_multi.hip
+    int n_info, info_bytes;                   // GK instantiations: data bits K (information + CRC) and bytes of a packed information row, (K - 8) / 8
     int prio;                                 // wave priority 0..3 (es_set_option "scl_prio"): a later launch of a burst may overtake an earlier one
 };
 
-constexpr int MWIN_W = KINFO / 32;            // trace-back windows
-// aux slab per path: windows 14 x (4 + 2) B, partial-sum blocks of 128 / 256 / 512 bits 28 x 4 B, fold scratch 16 x 4 B
-constexpr int WIDE_AUX_PER_PATH = MWIN_W * 6 + 28 * 4 + 16 * 4;
+constexpr int MWIN_W = KINFO / 32;            // trace-back windows of the default code (448 data bits)
+constexpr int MWIN_MAX = N / 32;              // ... of any code (GK instantiations: K data bits, 16 <= K <= 1024, K % 8 == 0)
+// aux slab per path: windows 32 x (4 + 2) B (14 used by the default code), partial-sum blocks of 128 / 256 / 512 bits 28 x 4 B, fold scratch 16 x 4 B
+constexpr int WIDE_AUX_PER_PATH = MWIN_MAX * 6 + 28 * 4 + 16 * 4;
 
 // NB = 2: buffers that a wave may still be reading while another wave is already a sort further (several waves per frame);
 // a block that is one wave runs in order and needs one of each.
@@ -268,6 +270,7 @@ __device__ __attribute__((noinline)) void f_level_exact(const double* par, doubl
 }
 
 // hard decision -> butterfly -> data bits -> CRC of one frame by one wave (fastpolar.py:260-268); returns the CRC verdict to every lane
+template <bool GK>
 __device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long ff, int lane, uint32_t* hardw, uint8_t* hbytes, const uint16_t* dpos)
 {
     const float* l32 = (const float*)a.llr + ff * N;
@@ -290,20 +293,21 @@ __device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long f
     }
     if (lane < 32) hardw[lane] = word;
     wave_fence_lds();
-    if (lane < 56) {
+    const int nib = GK ? a.info_bytes : ES_INFO_BYTES;                  // information bytes; the CRC byte follows them
+    for (int bi = lane; bi <= nib; bi += 64) {
         uint32_t byte = 0;
         #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const int pos = dpos[8 * lane + b];
+            const int pos = dpos[8 * bi + b];
             byte |= ((hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
         }
-        hbytes[lane] = (uint8_t)byte;
+        hbytes[bi] = (uint8_t)byte;
     }
     wave_fence_lds();
     int ok = 0;
-    if (lane == 0) ok = (crc8_bytes(hbytes, ES_INFO_BYTES) == hbytes[ES_INFO_BYTES]);
+    if (lane == 0) ok = (crc8_bytes(hbytes, nib) == hbytes[nib]);
     ok = __shfl(ok, 0);
-    if (lane < ES_INFO_BYTES) a.hard_info[ff * ES_INFO_BYTES + lane] = hbytes[lane];
+    for (int k = lane; k < nib; k += 64) a.hard_info[ff * nib + k] = hbytes[k];
     if (lane == 0) a.hard_ok[ff] = (uint8_t)ok;
     wave_fence_lds();
     return ok;
@@ -311,9 +315,14 @@ __device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long f
 
 // L lanes per block, LF paths per frame.  LF > 64: one frame per block, the block is the group (barrier = __syncthreads).
 // LF <= 64: every wave is a group of 64 / LF whole frames (barrier = wave fence), L / LF frames per block.
-template <int L, int LF>
+// GK: any code Polar(1024, K) + CRC-8 with K % 8 == 0 (the reference's PolarCode takes any K, rtwm/fastpolar.py:209-234): K, the row width
+// and the number of trace-back windows are run-time values (a.n_info, a.info_bytes).  The default instantiation (K = 448, everything the
+// reference itself instantiates) keeps them as compile-time constants: its code is unchanged by the existence of the other.
+template <int L, int LF, bool GK = false>
 __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
 {
+    constexpr int MW = GK ? MWIN_MAX : MWIN_W;           // rows of the trace-back arrays in the aux slab
+    const int NIB = GK ? a.info_bytes : ES_INFO_BYTES;   // bytes of a packed information row
     constexpr bool WAVE = (LF <= 64);                // the block is one wave
     constexpr int FRG = L / LF;                      // frames per block
     constexpr int NB = WAVE ? 1 : 2;
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
     double* const A = a.alpha + (long long)slot * N * L;             // element e of slot s at A[e*L + s]
     unsigned char* const aux = a.aux + (long long)slot * WIDE_AUX_PER_PATH * L;
     uint32_t* const TBW = reinterpret_cast<uint32_t*>(aux);                          // [14][L] window bits (first = MSB)
-    uint32_t* const BG = TBW + MWIN_W * L;                                           // [28][L] partial-sum blocks of 128 (rows 0..3), 256 (4..11) and 512 bits (12..27), by slot
+    uint32_t* const BG = TBW + MW * L;                                           // [28][L] partial-sum blocks of 128 (rows 0..3), 256 (4..11) and 512 bits (12..27), by slot
     uint32_t* const CB = BG + 28 * L;                                                // [16][L] fold scratch, own column only
     uint16_t* const TBA = reinterpret_cast<uint16_t*>(CB + 16 * L);                  // [14][L] path (within the frame) at the window's start
 
@@ -388,24 +397,24 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
             for (int fi = 0; fi < FRG; ++fi) {
                 const long long ff = g * FRG + fi;
                 if (ff >= a.B) break;
-                const int ok = hard_decision_wave(a, ff, lane, hd_words, hd_bytes, a.data_pos);
+                const int ok = hard_decision_wave<GK>(a, ff, lane, hd_words, hd_bytes, a.data_pos);
                 if (ok && a.skip_if_hard_ok) {                 // no list for this record: its candidate rows read as zeros
                     if (lane == 0) a.ncand[ff] = 0;
                     #pragma unroll 1
-                    for (int k = lane; k < a.lsz * ES_INFO_BYTES; k += 64) a.cand_info[ff * a.lsz * ES_INFO_BYTES + k] = 0;
+                    for (int k = lane; k < a.lsz * NIB; k += 64) a.cand_info[ff * a.lsz * NIB + k] = 0;
                     #pragma unroll 1
                     for (int k = lane; k < a.lsz; k += 64) { a.cand_metric[ff * a.lsz + k] = 0.0; a.cand_ok[ff * a.lsz + k] = 0; }
                 } else active_mask |= 1ULL << fi;
             }
         } else {
             if (wv == 0) {
-                const int ok = hard_decision_wave(a, f, lane, hd_words, hd_bytes, a.data_pos);
+                const int ok = hard_decision_wave<GK>(a, f, lane, hd_words, hd_bytes, a.data_pos);
                 if (lane == 0) W.flag = ok;
             }
             __syncthreads();
             if (W.flag && a.skip_if_hard_ok) {
                 if (p == 0) a.ncand[f] = 0;
-                for (int k = p; k < a.lsz * ES_INFO_BYTES; k += L) a.cand_info[f * a.lsz * ES_INFO_BYTES + k] = 0;
+                for (int k = p; k < a.lsz * NIB; k += L) a.cand_info[f * a.lsz * NIB + k] = 0;
                 if (p < a.lsz) { a.cand_metric[f * a.lsz + p] = 0.0; a.cand_ok[f * a.lsz + p] = 0; }
             } else active_mask = 1ULL;
             __syncthreads();
@@ -755,9 +764,37 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
             const double mk = W.skey[0][2 * (fp0 + k)];
             rank += ((mk < metric) || (mk == metric && k < pl)) ? 1 : 0;
         }
+        if constexpr (GK) {
+            const int r = a.n_info & 31;                             // a last, partial window: its bits move up to the MSB end like a full one's
+            if (r) { TBW[(a.n_info >> 5) * L + p] = hist << (32 - r); TBA[(a.n_info >> 5) * L + p] = (uint16_t)anc; }
+            group_sync();
+        }
         if (pl < cnt && f_store) {
-            uint8_t* out = a.cand_info + (f * a.lsz + rank) * ES_INFO_BYTES;
+            uint8_t* out = a.cand_info + (f * a.lsz + rank) * NIB;
             int curp = pl;
+            if constexpr (GK) {
+                const int nw = (a.n_info + 31) >> 5;
+                uint32_t reg = 0, crc_byte = 0;
+                #pragma unroll 1
+                for (int w = nw - 1; w >= 0; --w) {                  // windows are read last to first (each names its ancestor in the one before) ...
+                    const uint32_t wd = TBW[w * L + fp0 + curp];
+                    curp = (int)TBA[w * L + fp0 + curp] & (LF - 1);
+                    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = 4 * w + q;
+                        const uint32_t byte = (wd >> (24 - 8 * q)) & 0xffu;
+                        if (k < NIB) out[k] = (uint8_t)byte; else if (k == NIB) crc_byte = byte;
+                    }
+                }
+                #pragma unroll 1
+                for (int k = 0; k < NIB; ++k) {                      // ... and the CRC runs first to last over the row just written (this lane's own bytes)
+                    reg ^= out[k];
+                    #pragma unroll
+                    for (int b = 0; b < 8; ++b) reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
+                }
+                a.cand_metric[f * a.lsz + rank] = metric;
+                a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == crc_byte);
+            } else {
             uint32_t wd[MWIN_W];
             #pragma unroll
             for (int w = MWIN_W - 1; w >= 0; --w) {
@@ -775,6 +812,7 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
             }
             a.cand_metric[f * a.lsz + rank] = metric;
             a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == (wd[MWIN_W - 1] & 0xffu));
+            }
         }
         if (pl == 0 && f_store) a.ncand[f] = cnt;
         group_sync();
@@ -787,7 +825,7 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
     if (p == 0) atomicAnd(&a.slot_bits[slot >> 5], ~(1u << (slot & 31)));
 }
 
-template <int L, int LF>
+template <int L, int LF, bool GK = false>
 int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
 {
     const size_t lds = sizeof(WideLds<L, (LF > 64 ? 2 : 1)>);
@@ -795,9 +833,9 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
     static_assert((sizeof(WideLds<128, 2>) + 1279) / 1280 * 1280 * 6 <= 160 * 1024, "six two-wave workgroups per CU at L = 128");
     static_assert((sizeof(WideLds<64, 1>) + 1279) / 1280 * 1280 * 12 <= 160 * 1024, "twelve one-wave workgroups per CU");
     static_assert((LF & (LF - 1)) == 0, "power of two");
-    constexpr unsigned attr_bit = (unsigned)LF;                        // one instantiation per list capacity
+    constexpr unsigned attr_bit = (unsigned)LF << (GK ? 9 : 0);        // one instantiation per list capacity (and per kind of code)
     if (!(ctx->wide_attr_mask & attr_bit)) {                           // per context (= per device): the attribute belongs to the device's copy of the kernel
-        ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_scl_wide_kernel<L, LF>),
+        ES_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&es_scl_wide_kernel<L, LF, GK>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->wide_attr_mask |= attr_bit;
     }
@@ -811,7 +849,7 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
     a.n_slots = ctx->wide_slots * (Lm / L);
     a.slot_words = (a.n_slots + 31) / 32;
     { const int rc = es_slab_enter(ctx, 1, 0x300 | L, true, st); if (rc) return rc; }       // slot stride depends on the block's lanes only
-    hipLaunchKernelGGL((es_scl_wide_kernel<L, LF>), dim3((unsigned)blocks), dim3(L), lds, st, a);
+    hipLaunchKernelGGL((es_scl_wide_kernel<L, LF, GK>), dim3((unsigned)blocks), dim3(L), lds, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
@@ -845,7 +883,20 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
     a.skip_if_hard_ok = skip_if_hard_ok;
     a.lsz = L;
     a.prio = ctx->scl_prio;
+    a.n_info = ctx->n_info; a.info_bytes = ctx->n_info / 8 - 1;
     int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
+    if (ctx->n_info != KINFO) switch (LP) {               // a code other than the reference's own K = 448: the run-time-K instantiations
+        case 1:   return launch_wide<64, 1, true>(ctx, a, B, st);
+        case 2:   return launch_wide<64, 2, true>(ctx, a, B, st);
+        case 4:   return launch_wide<64, 4, true>(ctx, a, B, st);
+        case 8:   return launch_wide<64, 8, true>(ctx, a, B, st);
+        case 16:  return launch_wide<64, 16, true>(ctx, a, B, st);
+        case 32:  return launch_wide<64, 32, true>(ctx, a, B, st);
+        case 64:  return launch_wide<64, 64, true>(ctx, a, B, st);
+        case 128: return launch_wide<128, 128, true>(ctx, a, B, st);
+        case 256: return launch_wide<256, 256, true>(ctx, a, B, st);
+        default: ctx->err = "list_size must be in 1..256"; return ES_EINVAL;
+    }
     switch (LP) {
         case 1:   return launch_wide<64, 1>(ctx, a, B, st);
         case 2:   return launch_wide<64, 2>(ctx, a, B, st);

@@ -68,7 +68,7 @@ def _ptr(t: torch.Tensor | None) -> int | None:
 
 @dataclass
 class SclResult:
-    hard_info: torch.Tensor    # [B,55] uint8
+    hard_info: torch.Tensor    # [B,55] uint8 (engines of another code: [B, K/8 - 1])
     hard_ok: torch.Tensor      # [B] uint8
     cand_info: torch.Tensor    # [B,L,55] uint8, ascending metric
     cand_metric: torch.Tensor  # [B,L] float64
@@ -97,8 +97,11 @@ class SyncResult:
 
 
 class RxEngine:
-    def __init__(self, device: int | torch.device = 0, *, list_size_max: int = 32, fs: int = 48_000):
-        """list_size_max: the largest list `scl` will be asked for (sizes the list decoder's scratch: 0.4 GB, above 32 another 1.6 GB);
+    def __init__(self, device: int | torch.device = 0, *, list_size_max: int = 32, fs: int = 48_000, code_k: int = 448):
+        """code_k: information positions of the polar code (data bits + CRC-8).  448 is the reference's own code (rtwm/polar_fast.py:8-9);
+        any other 16 <= K <= 1016 with K % 8 == 0 (PolarCode(1024, K), rtwm/fastpolar.py:209-234) makes an engine whose `scl` is the only
+        FEC entry point (rows of K/8 - 1 bytes), on the lane-per-path kernel: it needs list_size_max > 32 or the "scl_lane_slab" option.
+        list_size_max: the largest list `scl` will be asked for (sizes the list decoder's scratch: 0.4 GB, above 32 another 1.6 GB);
         0 = a front-end engine (everything but `scl`, no list-decoder scratch): what a pipeline's band-pass / sync / demodulator streams use."""
         if not torch.cuda.is_available():
             raise nat.NativeError("RxEngine needs a ROCm GPU: torch.cuda.is_available() is False")
@@ -109,11 +112,13 @@ class RxEngine:
             raise nat.NativeError("es_create failed: " + (self._lib.es_last_error(None) or b"?").decode())
         self.list_size_max = int(list_size_max)
         self.fs = fs
-        ba, tpl, taps, ntaps, frozen = pack_tables(fs)
+        self.code_k = int(code_k)
+        ba, tpl, taps, ntaps, frozen = pack_tables(fs, self.code_k)
         self._tables = (ba, tpl, taps, ntaps, frozen)       # keep host arrays alive
         nat.check(self._ctx, self._lib.es_set_tables(
             self._ctx, ba.ctypes.data, tpl.ctypes.data, taps.ctypes.data, ntaps.ctypes.data,
             frozen.ctypes.data), "es_set_tables")
+        self.info_bytes = int(self._lib.es_info_bytes(self._ctx))
 
     def set_option(self, name: str, value: int) -> None:
         """Tuning knobs of the native library (results never depend on them); see include/echoseal_hip.h."""
@@ -315,8 +320,8 @@ class RxEngine:
         B, L = llr.shape[0], int(list_size)
         dev = self.device
         res = SclResult(
-            torch.empty((B, 55), dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.uint8, device=dev),
-            torch.empty((B, L, 55), dtype=torch.uint8, device=dev), torch.empty((B, L), dtype=torch.float64, device=dev),
+            torch.empty((B, self.info_bytes), dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.uint8, device=dev),
+            torch.empty((B, L, self.info_bytes), dtype=torch.uint8, device=dev), torch.empty((B, L), dtype=torch.float64, device=dev),
             torch.empty((B, L), dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.int32, device=dev))   # every row is written by the kernel
         nat.check(self._ctx, self._lib.es_scl_batch(
             self._ctx, _ptr(llr), dt, B, L, int(bool(skip_if_hard_ok)), _ptr(res.hard_info), _ptr(res.hard_ok),

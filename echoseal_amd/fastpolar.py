@@ -30,6 +30,24 @@ def default_engine():
     return _engine
 
 
+_other = None          # (K, engine) of the last code other than the reference's own that `decode` was asked for
+
+
+def engine_for(K: int):
+    """The engine `PolarCode(1024, K).decode` runs on: the process-wide one for K = 448, else one engine built for that K (one at a time:
+    each holds ~1.1 GB of list-decoder scratch; asking for another K closes it)."""
+    global _other
+    if K == 448:
+        return default_engine()
+    if _other is None or _other[0] != K:
+        import torch
+        from .engine import RxEngine
+        if _other is not None:
+            _other[1].close()
+        _other = (K, RxEngine(torch.cuda.current_device() if torch.cuda.is_available() else 0, list_size_max=256, code_k=K))
+    return _other[1]
+
+
 def _reliability_order(N: int) -> np.ndarray:
     rel = np.asarray(Q_NMAX_1024, dtype=np.int64)
     if rel.size != N:
@@ -104,11 +122,11 @@ class PolarCode:
         llr = np.asarray(llr)
         if llr.ndim != 1 or llr.size != self.N:
             raise ValueError(f"llr must be 1D length {self.N}")
-        if (self.N, self.K, self.crc_size) != (1024, 448, 8):
-            raise NotImplementedError("the HIP decoder is built for Polar(1024,448)+CRC-8")
+        if self.N != 1024 or self.crc_size != 8 or self.K % 8 or not 16 <= self.K <= 1016:
+            raise NotImplementedError("the HIP decoder serves Polar(1024, K) + CRC-8 with K % 8 == 0 and 16 <= K <= 1016 (DESIGN.md section 7)")
         import torch
         from .engine import select_payload
-        eng = default_engine()
+        eng = engine_for(self.K)
         if self.list_size > eng.list_size_max:
             raise NotImplementedError(f"list_size={self.list_size}: the HIP decoder supports list sizes up to {eng.list_size_max}")
         host = np.ascontiguousarray(llr, dtype=np.float32 if llr.dtype == np.float32 else np.float64)

@@ -67,7 +67,7 @@ def frozen_mask(N: int = 1024, K: int = 448) -> np.ndarray:
     return mask
 
 
-def pack_tables(fs: int = 48_000):
+def pack_tables(fs: int = 48_000, K: int = 448):
     """Arrays in the layout es_set_tables() expects."""
     ba = np.zeros((4, 18), dtype=np.float64)
     tpl = np.zeros((4, 63), dtype=np.float64)
@@ -80,4 +80,4 @@ def pack_tables(fs: int = 48_000):
         h = matched_filter_taps(band, fs)
         taps[i, : h.size] = h
         ntaps[i] = h.size
-    return ba, tpl, taps, ntaps, frozen_mask().astype(np.uint8)
+    return ba, tpl, taps, ntaps, frozen_mask(1024, K).astype(np.uint8)

@@ -22,15 +22,19 @@
 
 #define NN 1024
 #define NLEV 10
-#define KK 448
+#define KMAX 1024
 #define CRC 8
-#define INFO (KK - CRC)
+/* K (information + CRC bits) is 448 in everything the reference instantiates (rtwm/polar_fast.py:18-24); PolarCode itself takes any
+ * 0 < K <= N (rtwm/fastpolar.py:209-234) and eso_polar_set_k follows it there (the tests of other K). */
+static int g_K = 448;
+#define KK g_K
+#define INFO (g_K - CRC)
 
 static const uint64_t EXPTAB[ES_EXP_TAB_WORDS] = ES_EXP_TAB_INIT;
 
 static int g_tables_ready = 0;
 static uint8_t g_frozen[NN];
-static int32_t g_data_pos[KK];
+static int32_t g_data_pos[KMAX];
 
 /* rtwm/fastpolar.py:220-230 -- frozen = all True; frozen[rel[:K]] = False (the K LEAST reliable
  * indices become information positions); _data_pos = flatnonzero(~frozen) (ascending index). */
@@ -48,7 +52,15 @@ void eso_polar_tables(uint8_t* frozen, int32_t* data_pos)
 {
     build_tables();
     memcpy(frozen, g_frozen, NN);
-    memcpy(data_pos, g_data_pos, sizeof g_data_pos);
+    memcpy(data_pos, g_data_pos, sizeof(int32_t) * (size_t)g_K);
+}
+
+/* K of the code the following calls use (default 448); returns the previous value */
+int eso_polar_set_k(int K)
+{
+    const int old = g_K;
+    if (K > CRC && K <= KMAX && K != g_K) { g_K = K; g_tables_ready = 0; build_tables(); }
+    return old;
 }
 
 /* rtwm/fastpolar.py:362-371 -- CRC-8, poly 0x07, init 0, MSB first, no reflection. */
@@ -95,7 +107,7 @@ static int crc_ok(const uint8_t* data448)
 int eso_polar_hard(const double* llr, uint8_t* info440)
 {
     build_tables();
-    uint8_t x[NN], data[KK];
+    uint8_t x[NN], data[KMAX];
     for (int i = 0; i < NN; i++) x[i] = llr[i] > 0.0;
     eso_polar_transform(x);
     for (int i = 0; i < KK; i++) data[i] = x[g_data_pos[i]];
@@ -221,7 +233,7 @@ int eso_scl_list(const double* llr, int L, uint8_t* cand_info, double* cand_metr
     stable_sort_cands(order, npaths);
     for (int r = 0; r < npaths; r++) {
         const path_t* p = paths[order[r].idx];
-        uint8_t data[KK];
+        uint8_t data[KMAX];
         for (int j = 0; j < KK; j++) data[j] = p->u[g_data_pos[j]];
         memcpy(cand_info + (size_t)r * INFO, data, INFO);
         cand_metric[r] = p->metric;
@@ -236,7 +248,7 @@ int eso_scl_list(const double* llr, int L, uint8_t* cand_info, double* cand_metr
  * `took_list` (nullable) reports whether the list loop ran. */
 int eso_polar_decode(const double* llr, int L, uint8_t* info440, int* took_list)
 {
-    uint8_t hard[INFO];
+    uint8_t hard[KMAX];
     if (took_list) *took_list = 0;
     if (eso_polar_hard(llr, hard)) { memcpy(info440, hard, INFO); return 1; }   /* :268-276 */
     if (took_list) *took_list = 1;

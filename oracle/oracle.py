@@ -60,30 +60,42 @@ def sum_f32(a): a = _c(a, np.float32); return np.float32(lib().eso_sum_f32(_p(a)
 
 
 # ------------------------------------------------------------------------------- polar
+_K = [448]                        # K of the code the polar functions below use (eso_polar_set_k); 448 unless a test says otherwise
+
+
+class code_k:
+    """`with oracle.code_k(512): ...` -- the polar functions inside use Polar(1024, 512)+CRC-8 (rtwm/fastpolar.py:209-234 takes any K)."""
+    def __init__(self, K): self.K = int(K)
+    def __enter__(self): self.old = lib().eso_polar_set_k(self.K); _K[0] = self.K; return self
+    def __exit__(self, *exc): lib().eso_polar_set_k(self.old); _K[0] = self.old
+
+
 def polar_tables():
-    frozen = np.zeros(1024, np.uint8); dpos = np.zeros(448, np.int32)
+    frozen = np.zeros(1024, np.uint8); dpos = np.zeros(_K[0], np.int32)
     lib().eso_polar_tables(_p(frozen), _p(dpos)); return frozen.astype(bool), dpos
 
 def polar_encode(info_bits):
     info = _c(info_bits, np.uint8); code = np.zeros(1024, np.uint8)
+    if info.size != _K[0] - 8:
+        raise ValueError(f"need {_K[0] - 8} information bits")
     lib().eso_polar_encode(_p(info), _p(code)); return code
 
 def crc8(bits): b = _c(bits, np.uint8); return int(lib().eso_crc8(_p(b), int(b.size)))
 
 def polar_hard(llr):
-    llr = _c(llr, np.float64); info = np.zeros(440, np.uint8)
+    llr = _c(llr, np.float64); info = np.zeros(_K[0] - 8, np.uint8)
     ok = lib().eso_polar_hard(_p(llr), _p(info)); return info, bool(ok)
 
 def scl_list(llr, L):
-    """-> (n, info[L,440], metric[L], crc[L]) in ascending-metric (stable) order."""
+    """-> (n, info[L,K-8], metric[L], crc[L]) in ascending-metric (stable) order."""
     llr = _c(llr, np.float64)
-    ci = np.zeros((L, 440), np.uint8); cm = np.zeros(L); cc = np.zeros(L, np.uint8)
+    ci = np.zeros((L, _K[0] - 8), np.uint8); cm = np.zeros(L); cc = np.zeros(L, np.uint8)
     n = lib().eso_scl_list(_p(llr), int(L), _p(ci), _p(cm), _p(cc))
     return n, ci, cm, cc
 
 def polar_decode(llr, L):
-    """PolarCode.decode(llr, validator=None) -> (info bits[440], ok, took_list)."""
-    llr = _c(llr, np.float64); info = np.zeros(440, np.uint8); tl = ctypes.c_int(0)
+    """PolarCode.decode(llr, validator=None) -> (info bits[K-8], ok, took_list)."""
+    llr = _c(llr, np.float64); info = np.zeros(_K[0] - 8, np.uint8); tl = ctypes.c_int(0)
     ok = lib().eso_polar_decode(_p(llr), int(L), _p(info), ctypes.byref(tl))
     return info, bool(ok), bool(tl.value)
 

@@ -3,7 +3,7 @@
 REFERENCE, captured by running it (build container only; /root/reference is read-only and never travels).  Only inputs
 and outputs are stored under tests/golden/ -- no reference source.
 
-    python -m oracle.refshim.gen_golden_r3 [all|inputs|sweep_default|sweep_glibc]
+    python -m oracle.refshim.gen_golden_r3 [all|inputs|sweep_default|sweep_glibc|codes]
 
     polar_sweep_{default,glibc}.npz   for each L in (1, 4, 16): 256 LLR vectors through the reference's
         PolarCode.decode(list_size=L) (rtwm/fastpolar.py:254-359): (info, ok), whether the list loop ran, and the final
@@ -16,6 +16,11 @@ and outputs are stored under tests/golden/ -- no reference source.
           64  AWGN on random codewords, sigma 0.3 .. 1.1, clipped to +-12
           64  tie-heavy (few distinct magnitudes, zeros, +-12)
         Both NumPy run-time modes (see gen_golden.py: `default` = AVX-512 exp/log1p dispatch, `glibc` = C library).
+
+    polar_codes_{default,glibc}.npz   PolarCode(1024, K, list_size=L, crc_size=8).decode for K in (16, 64, 200, 512, 1000) -- the
+        reference's PolarCode takes any K (rtwm/fastpolar.py:209-234); byte-aligned K is what rtwm/polar_fast.py can round-trip -- and
+        L in (1, 8): six LLR vectors per K (codeword in light / heavy AWGN, garbage, +-12 ties on a codeword with flips, a clean
+        codeword at +-3, zeros), (info, ok), whether the list loop ran, and the final list.
 """
 from __future__ import annotations
 
@@ -152,6 +157,68 @@ def gen_sweep(mode, workers=6):
     np.savez_compressed(os.path.join(GOLD, f"polar_sweep_{mode}.npz"), **out)
 
 
+CODES_K = (16, 64, 200, 512, 1000)
+CODES_L = (1, 8)
+
+
+def gen_codes(mode):
+    import builtins
+    import numpy as np
+    from oracle.refshim.shim import load_reference
+    load_reference()
+    import rtwm.fastpolar as fp
+    captured = {}
+
+    def spy_sorted(seq, key=None):
+        out = builtins.sorted(seq, key=key)
+        if seq and hasattr(seq[0], "metric"):
+            captured["metric"] = np.array([p.metric for p in out], dtype=np.float64)
+            captured["u"] = np.stack([p.u.copy() for p in out])
+        return out
+    fp.sorted = spy_sorted
+    out = {"meta_mode": np.array(mode), "meta_numpy": np.array(np.__version__), "ks": np.array(CODES_K), "lists": np.array(CODES_L)}
+    for K in CODES_K:
+        rng = np.random.default_rng(4000 + K)
+        enc = fp.PolarCode(1024, K, list_size=1, crc_size=8)
+        rows = []
+        for kind in range(6):
+            code = enc.encode(rng.integers(0, 2, K - 8, dtype=np.uint8)).astype(np.float64)
+            if kind == 0: v = np.clip(2.0 * (2.0 * code - 1.0 + rng.normal(0, 0.5, 1024)) / 0.25, -12, 12)
+            elif kind == 1: v = np.clip(2.0 * (2.0 * code - 1.0 + rng.normal(0, 1.0, 1024)) / 1.0, -12, 12)
+            elif kind == 2: v = np.clip(rng.normal(0, 3.0, 1024), -12, 12)
+            elif kind == 3:
+                flips = rng.random(1024) < 0.05
+                v = (2.0 * np.logical_xor(code > 0, flips) - 1.0) * 12.0
+            elif kind == 4: v = (2.0 * code - 1.0) * 3.0
+            else: v = np.zeros(1024)
+            rows.append(v.astype(np.float32))
+        llrs = np.stack(rows)
+        if mode == "glibc":
+            out[f"K{K}/llr"] = llrs
+        for L in CODES_L:
+            pc = fp.PolarCode(1024, K, list_size=L, crc_size=8)
+            nb = (K - 8 + 7) // 8
+            n = llrs.shape[0]
+            info = np.zeros((n, nb), np.uint8); ok = np.zeros(n, bool); took = np.zeros(n, bool)
+            ci = np.zeros((n, L, nb), np.uint8); cm = np.zeros((n, L)); cc = np.zeros((n, L), np.uint8); nc = np.zeros(n, np.int32)
+            for i in range(n):
+                captured.clear()
+                bits, okk = pc.decode(llrs[i])
+                info[i] = np.packbits(bits); ok[i] = bool(okk)
+                if captured:
+                    took[i] = True
+                    data = captured["u"][:, pc._data_pos]
+                    k = data.shape[0]; nc[i] = k
+                    ci[i, :k] = np.packbits(data[:, :K - 8], axis=1)
+                    cm[i, :k] = captured["metric"]
+                    cc[i, :k] = [pc._crc_ok(d[:K - 8], d[K - 8:K]) for d in data]
+            t = f"K{K}/L{L}"
+            out.update({f"{t}/info": info, f"{t}/ok": ok, f"{t}/took_list": took, f"{t}/cand_info": ci, f"{t}/cand_metric": cm,
+                        f"{t}/cand_crc": cc, f"{t}/ncand": nc})
+            print(f"  codes[{mode}] K={K} L={L}: ok {int(ok.sum())} list {int(took.sum())}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, f"polar_codes_{mode}.npz"), **out)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
@@ -163,6 +230,12 @@ def main():
         os.remove(INPUTS)                                             # (the inputs live in polar_sweep_glibc.npz)
     elif what == "inputs":
         gen_inputs()
+    elif what == "codes":
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "codes_default"], cwd=ROOT, env=env)
+        env["NPY_DISABLE_CPU_FEATURES"] = AVX512_OFF
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "codes_glibc"], cwd=ROOT, env=env)
+    elif what in ("codes_default", "codes_glibc"):
+        gen_codes(what.split("_")[1])
     elif what in ("sweep_default", "sweep_glibc"):
         gen_sweep(what.split("_")[1], workers=int(os.environ.get("GOLD_WORKERS", "6")))
     else:

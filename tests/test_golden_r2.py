@@ -209,6 +209,40 @@ def test_polar_sweep_matches_reference(oracle, mode, L):
     assert flips <= 2, flips
 
 
+@pytest.mark.parametrize("mode", ["default", "glibc"])
+def test_other_codes_match_reference(oracle, mode):
+    """PolarCode(1024, K) for K other than the detector's 448 (the reference's class takes any K, rtwm/fastpolar.py:209-234): K = 16, 64, 200,
+    512, 1000 at list sizes 1 and 8, six vectors each (clean, noisy, noise only, bit flips at +-12, constant magnitude, all zero) through the
+    reference's decode (oracle/refshim/gen_golden_r3.py codes)."""
+    g = _g(f"polar_codes_{mode}.npz"); gl = _g("polar_codes_glibc.npz")
+    listed = 0
+    for K in g["ks"]:
+        llrs = gl[f"K{K}/llr"].astype(np.float64)
+        with oracle.code_k(int(K)):
+            for L in g["lists"]:
+                t = f"K{K}/L{L}"
+                for i in range(llrs.shape[0]):
+                    info, ok, took = oracle.polar_decode(llrs[i], int(L))
+                    assert took == bool(g[f"{t}/took_list"][i]), (t, i)
+                    if not took:
+                        assert ok == bool(g[f"{t}/ok"][i]) and np.array_equal(np.packbits(info), g[f"{t}/info"][i]), (t, i)
+                        continue
+                    listed += 1
+                    nn, ci, cm, cc = oracle.scl_list(llrs[i], int(L))
+                    assert nn == int(g[f"{t}/ncand"][i]), (t, i)
+                    same_bits = np.array_equal(np.packbits(ci, axis=1), g[f"{t}/cand_info"][i][:nn])
+                    if mode == "glibc":
+                        assert same_bits and np.array_equal(cm.view(np.uint64), g[f"{t}/cand_metric"][i][:nn].view(np.uint64)), (t, i)
+                        assert np.array_equal(cc, g[f"{t}/cand_crc"][i][:nn]), (t, i)
+                    if same_bits:                  # (NumPy's own exp/log1p may break an exact tie the other way: the all-zero / constant rows)
+                        assert np.allclose(cm, g[f"{t}/cand_metric"][i][:nn], rtol=1e-12, atol=0), (t, i)
+                        assert ok == bool(g[f"{t}/ok"][i]) and np.array_equal(np.packbits(info), g[f"{t}/info"][i]), (t, i)
+                    else:
+                        assert i >= 3, (t, i)
+    assert oracle.polar_tables()[1].size == 448          # the context manager put the detector's code back
+    assert listed >= 30
+
+
 def _scl_result_from_oracle(oracle, llr, L):
     from echoseal_amd.engine import SclResult
     hinfo, hok = oracle.polar_hard(llr.astype(np.float64))

@@ -137,6 +137,35 @@ def test_polar_sweep_vs_reference(engine, L):
         assert np.array_equal(ok.cpu().numpy() == 1, g[f"L{L}/ok"]), multi
 
 
+def test_other_codes_vs_reference():
+    """PolarCode(1024, K) for K = 16, 64, 200, 512, 1000 (the reference's class takes any K; its detector uses 448): the run-time-K
+    instantiation of the lane-per-path kernel against the reference's lists (C-library exp/log1p): bits, metrics and CRC flags identical, and
+    (info, ok) through the host-side tail of PolarCode.decode."""
+    from echoseal_amd.engine import RxEngine, select_payload
+    g = _g("polar_codes_glibc.npz")
+    for K in g["ks"]:
+        eng = RxEngine(0, list_size_max=64, code_k=int(K))
+        assert eng.info_bytes == int(K) // 8 - 1
+        llr, = _dev(eng, g[f"K{K}/llr"])
+        for L in g["lists"]:
+            t = f"K{K}/L{L}"
+            took = g[f"{t}/took_list"]
+            res = eng.scl(llr, list_size=int(L), skip_if_hard_ok=False).check()
+            short = eng.scl(llr, list_size=int(L), skip_if_hard_ok=True).check()
+            assert np.array_equal(short.ncand.cpu().numpy() > 0, took), t
+            nc = g[f"{t}/ncand"]
+            for i in np.flatnonzero(took):
+                n = int(nc[i])
+                assert int(res.ncand[i]) == n, (t, i)
+                assert np.array_equal(res.cand_info[i, :n].cpu().numpy(), g[f"{t}/cand_info"][i, :n]), (t, i)
+                assert np.array_equal(res.cand_metric[i, :n].cpu().numpy().view(np.uint64), g[f"{t}/cand_metric"][i, :n].view(np.uint64)), (t, i)
+                assert np.array_equal(res.cand_ok[i, :n].cpu().numpy(), g[f"{t}/cand_crc"][i, :n]), (t, i)
+            for i in range(llr.shape[0]):
+                payload, ok = select_payload(short, i, None)
+                assert ok == bool(g[f"{t}/ok"][i]) and payload == g[f"{t}/info"][i].tobytes(), (t, i)
+        eng.close()
+
+
 def test_decode_with_validator_vs_reference(engine):
     from echoseal_amd.engine import select_payload
     from test_golden_r2 import _validator

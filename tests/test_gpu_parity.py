@@ -355,6 +355,53 @@ def test_scl_wide_lists_vs_oracle(oracle, L):
     eng.close()
 
 
+@pytest.mark.parametrize("K", [16, 24, 40, 64, 200, 440, 456, 512, 1000, 1016])
+def test_scl_other_codes_vs_oracle(oracle, K):
+    """Polar(1024, K) + CRC-8 for K other than 448 (whole bytes; a last trace-back window of 8, 16 or 24 bits; one or 32 windows): lists of every
+    capacity against the oracle built for the same K, float32 and float64 LLRs, ragged batch sizes, and the API's PolarCode.decode."""
+    from echoseal_amd.engine import RxEngine
+    from rtwm.fastpolar import PolarCode
+    eng = RxEngine(0, list_size_max=256, code_k=K)
+    rng = np.random.default_rng(900 + K)
+    pc = PolarCode(1024, K, list_size=8, crc_size=8)
+    B = 37
+    codes = np.stack([pc.encode(rng.integers(0, 2, K - 8, dtype=np.uint8)) for _ in range(B)]).astype(np.float64)
+    llr = np.clip(2.0 * (2.0 * codes - 1.0 + rng.normal(0, 0.9, codes.shape)) / 0.81, -12, 12)
+    llr[0] = 0.0
+    llr[1] = np.where(codes[1] > 0, 12.0, -12.0)
+    llr[2] = np.clip(rng.normal(0, 3, 1024), -12, 12)
+    llr[3] = np.where(codes[3] > 0, 1.0, -1.0) * rng.integers(1, 4, 1024)       # small integers: ties
+    with oracle.code_k(K):
+        for L, dt in ((1, np.float32), (2, np.float64), (8, np.float32), (8, np.float64), (32, np.float32), (50, np.float32), (256, np.float64)):
+            x = llr.astype(dt)[: (B if L <= 8 else 9)]
+            res = eng.scl(torch.from_numpy(x).to(eng.device), list_size=L, skip_if_hard_ok=False).check()
+            short = eng.scl(torch.from_numpy(x).to(eng.device), list_size=L, skip_if_hard_ok=True).check()
+            assert res.cand_info.shape[-1] == K // 8 - 1
+            for i in range(x.shape[0]):
+                hinfo, hok = oracle.polar_hard(x[i].astype(np.float64))
+                assert np.packbits(hinfo).tobytes() == res.hard_info[i].cpu().numpy().tobytes() and hok == bool(res.hard_ok[i]), (L, i)
+                assert (int(short.ncand[i]) == 0) == hok, (L, i)
+                nn, ci, cm, cc = oracle.scl_list(x[i].astype(np.float64), L)
+                assert int(res.ncand[i]) == nn, (L, i)
+                assert np.array_equal(cm[:nn], res.cand_metric[i, :nn].cpu().numpy()), (L, i)
+                assert np.array_equal(np.packbits(ci[:nn], axis=1), res.cand_info[i, :nn].cpu().numpy()), (L, i)
+                assert np.array_equal(cc[:nn], res.cand_ok[i, :nn].cpu().numpy()), (L, i)
+        # the drop-in class (its own engine for this K), against the oracle's PolarCode.decode
+        for i in (1, 4, 5):
+            bits, ok = pc.decode(llr[i])
+            info, ook, _ = oracle.polar_decode(llr[i], 8)
+            assert ok == ook and np.array_equal(bits, info), i
+    # entry points that only exist for the detector's code say so
+    import echoseal_amd._native as nat
+    with pytest.raises(nat.NativeError, match="reference's own code"):
+        eng.polar_encode(torch.zeros((1, 55), dtype=torch.uint8, device=eng.device))
+    eng.close()
+    small = RxEngine(0, list_size_max=8, code_k=K)
+    with pytest.raises(nat.NativeError, match="lane-per-path kernel only"):
+        small.scl(torch.zeros((1, 1024), device=small.device), list_size=8)
+    small.close()
+
+
 @pytest.mark.parametrize("mode", ["default", "glibc"])
 def test_scl_wide_matches_reference_golden(mode):
     import os
