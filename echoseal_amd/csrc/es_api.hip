@@ -48,7 +48,7 @@ extern "C" {
 
 int es_abi_version(void) { return 1; }
 
-int es_info_bytes(const es_ctx* ctx) { return (ctx && ctx->n_info >= 16) ? ctx->n_info / 8 - 1 : ES_INFO_BYTES; }
+int es_info_bytes(const es_ctx* ctx) { return (ctx && ctx->n_info >= 9) ? (ctx->n_info - 8 + 7) / 8 : ES_INFO_BYTES; }
 
 const char* es_last_error(const es_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -148,9 +148,9 @@ int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float*
         else dpos[n++] = (uint16_t)i;
     }
     // 448 is the reference's own code (rtwm/polar_fast.py:8-9); its PolarCode class takes any K (rtwm/fastpolar.py:209-234), and so does
-    // es_scl_batch for whole bytes of data around the CRC-8.  (K = 1024 has no frozen position at all and is not served.)
-    if (n < 16 || n > ES_POLAR_N - 8 || n % 8)
-        return fail(ctx, ES_EINVAL, "es_set_tables: the frozen mask must leave K information positions with 16 <= K <= 1016 and K % 8 == 0 (448 for every entry point but es_scl_batch)");
+    // es_scl_batch (at least one information bit in front of the CRC-8).
+    if (n < 9)
+        return fail(ctx, ES_EINVAL, "es_set_tables: the frozen mask must leave K >= 9 information positions (448 for every entry point but es_scl_batch)");
     ctx->n_info = n;
     DeviceGuard g(ctx->device);
     ES_HIP_CHECK(ctx, hipMemcpy(ctx->d_tables, &h, sizeof h, hipMemcpyHostToDevice));

@@ -71,7 +71,7 @@ struct WideArgs {
     int skip_if_hard_ok;
     int lsz;                                  // the caller's list size (<= L)
     unsigned* slot_bits; int n_slots, slot_words;   // bitmap of slab slots (one per resident block), as in es_scl_multi.hip
-    int n_info, info_bytes;                   // GK instantiations: data bits K (information + CRC) and bytes of a packed information row, (K - 8) / 8
+    int n_info, info_bytes;                   // GK instantiations: data bits K (information + CRC) and bytes of a packed information row, ceil((K - 8) / 8)
     int prio;                                 // wave priority 0..3 (es_set_option "scl_prio"): a later launch of a burst may overtake an earlier one
 };
 
@@ -293,21 +293,51 @@ __device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long f
     }
     if (lane < 32) hardw[lane] = word;
     wave_fence_lds();
-    const int nib = GK ? a.info_bytes : ES_INFO_BYTES;                  // information bytes; the CRC byte follows them
-    for (int bi = lane; bi <= nib; bi += 64) {
-        uint32_t byte = 0;
-        #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int pos = dpos[8 * bi + b];
-            byte |= ((hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
-        }
-        hbytes[bi] = (uint8_t)byte;
-    }
-    wave_fence_lds();
     int ok = 0;
-    if (lane == 0) ok = (crc8_bytes(hbytes, nib) == hbytes[nib]);
-    ok = __shfl(ok, 0);
-    for (int k = lane; k < nib; k += 64) a.hard_info[ff * nib + k] = hbytes[k];
+    if constexpr (GK) {
+        // K data bits (K - 8 information bits, then the CRC's 8), MSB first in ceil(K / 8) bytes; neither count need be a whole number of bytes
+        const int K = a.n_info, nbits = K - 8, nib = a.info_bytes, rem = nbits & 7;
+        for (int bi = lane; bi < ((K + 7) >> 3); bi += 64) {
+            uint32_t byte = 0;
+            #pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int j = 8 * bi + b;
+                const int pos = dpos[j < K ? j : 0];
+                if (j < K) byte |= ((hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
+            }
+            hbytes[bi] = (uint8_t)byte;
+        }
+        wave_fence_lds();
+        if (lane == 0) {
+            uint32_t reg = crc8_bytes(hbytes, nbits >> 3);
+            const uint32_t lo = hbytes[nbits >> 3], hi = (((nbits >> 3) + 1) < ((K + 7) >> 3)) ? hbytes[(nbits >> 3) + 1] : 0u;
+            for (int b = 0; b < rem; ++b) {
+                reg ^= ((lo >> (7 - b)) & 1u) << 7;
+                reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
+            }
+            ok = (reg == ((((lo << 8) | hi) >> (8 - rem)) & 0xffu));
+        }
+        ok = __shfl(ok, 0);
+        for (int k = lane; k < nib; k += 64) {
+            uint32_t v = hbytes[k];
+            if (rem && k == nib - 1) v &= 0xffu << (8 - rem);          // the row is np.packbits(information bits): zero padding, not CRC bits
+            a.hard_info[ff * nib + k] = (uint8_t)v;
+        }
+    } else {
+        if (lane < 56) {
+            uint32_t byte = 0;
+            #pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int pos = dpos[8 * lane + b];
+                byte |= ((hardw[pos >> 5] >> (pos & 31)) & 1u) << (7 - b);
+            }
+            hbytes[lane] = (uint8_t)byte;
+        }
+        wave_fence_lds();
+        if (lane == 0) ok = (crc8_bytes(hbytes, ES_INFO_BYTES) == hbytes[ES_INFO_BYTES]);
+        ok = __shfl(ok, 0);
+        if (lane < ES_INFO_BYTES) a.hard_info[ff * ES_INFO_BYTES + lane] = hbytes[lane];
+    }
     if (lane == 0) a.hard_ok[ff] = (uint8_t)ok;
     wave_fence_lds();
     return ok;
@@ -315,7 +345,7 @@ __device__ __forceinline__ int hard_decision_wave(const WideArgs& a, long long f
 
 // L lanes per block, LF paths per frame.  LF > 64: one frame per block, the block is the group (barrier = __syncthreads).
 // LF <= 64: every wave is a group of 64 / LF whole frames (barrier = wave fence), L / LF frames per block.
-// GK: any code Polar(1024, K) + CRC-8 with K % 8 == 0 (the reference's PolarCode takes any K, rtwm/fastpolar.py:209-234): K, the row width
+// GK: any code Polar(1024, K) + CRC-8, 9 <= K <= 1024 (the reference's PolarCode takes any K, rtwm/fastpolar.py:209-234): K, the row width
 // and the number of trace-back windows are run-time values (a.n_info, a.info_bytes).  The default instantiation (K = 448, everything the
 // reference itself instantiates) keeps them as compile-time constants: its code is unchanged by the existence of the other.
 template <int L, int LF, bool GK = false>
@@ -773,8 +803,8 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
             uint8_t* out = a.cand_info + (f * a.lsz + rank) * NIB;
             int curp = pl;
             if constexpr (GK) {
-                const int nw = (a.n_info + 31) >> 5;
-                uint32_t reg = 0, crc_byte = 0;
+                const int nw = (a.n_info + 31) >> 5, nbits = a.n_info - 8, rem = nbits & 7, kc = nbits >> 3;
+                uint32_t reg = 0, lo = 0, hi = 0;                    // lo, hi: the two bytes the 8 CRC bits lie in
                 #pragma unroll 1
                 for (int w = nw - 1; w >= 0; --w) {                  // windows are read last to first (each names its ancestor in the one before) ...
                     const uint32_t wd = TBW[w * L + fp0 + curp];
@@ -783,17 +813,22 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                     for (int q = 0; q < 4; ++q) {
                         const int k = 4 * w + q;
                         const uint32_t byte = (wd >> (24 - 8 * q)) & 0xffu;
-                        if (k < NIB) out[k] = (uint8_t)byte; else if (k == NIB) crc_byte = byte;
+                        if (k == kc) lo = byte; else if (k == kc + 1) hi = byte;
+                        if (k < NIB) out[k] = (uint8_t)((rem && k == NIB - 1) ? (byte & (0xffu << (8 - rem))) : byte);
                     }
                 }
                 #pragma unroll 1
-                for (int k = 0; k < NIB; ++k) {                      // ... and the CRC runs first to last over the row just written (this lane's own bytes)
+                for (int k = 0; k < kc; ++k) {                       // ... and the CRC runs first to last over the row just written (this lane's own bytes)
                     reg ^= out[k];
                     #pragma unroll
                     for (int b = 0; b < 8; ++b) reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
                 }
+                for (int b = 0; b < rem; ++b) {
+                    reg ^= ((lo >> (7 - b)) & 1u) << 7;
+                    reg = (reg & 0x80u) ? ((reg << 1) ^ 0x07u) & 0xffu : (reg << 1) & 0xffu;
+                }
                 a.cand_metric[f * a.lsz + rank] = metric;
-                a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == crc_byte);
+                a.cand_ok[f * a.lsz + rank] = (uint8_t)(reg == ((((lo << 8) | hi) >> (8 - rem)) & 0xffu));
             } else {
             uint32_t wd[MWIN_W];
             #pragma unroll
@@ -883,7 +918,7 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
     a.skip_if_hard_ok = skip_if_hard_ok;
     a.lsz = L;
     a.prio = ctx->scl_prio;
-    a.n_info = ctx->n_info; a.info_bytes = ctx->n_info / 8 - 1;
+    a.n_info = ctx->n_info; a.info_bytes = (ctx->n_info - 8 + 7) / 8;
     int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
     if (ctx->n_info != KINFO) switch (LP) {               // a code other than the reference's own K = 448: the run-time-K instantiations
         case 1:   return launch_wide<64, 1, true>(ctx, a, B, st);

@@ -68,7 +68,7 @@ def _ptr(t: torch.Tensor | None) -> int | None:
 
 @dataclass
 class SclResult:
-    hard_info: torch.Tensor    # [B,55] uint8 (engines of another code: [B, K/8 - 1])
+    hard_info: torch.Tensor    # [B,55] uint8 (engines of another code: [B, ceil((K - 8) / 8)])
     hard_ok: torch.Tensor      # [B] uint8
     cand_info: torch.Tensor    # [B,L,55] uint8, ascending metric
     cand_metric: torch.Tensor  # [B,L] float64
@@ -99,8 +99,9 @@ class SyncResult:
 class RxEngine:
     def __init__(self, device: int | torch.device = 0, *, list_size_max: int = 32, fs: int = 48_000, code_k: int = 448):
         """code_k: information positions of the polar code (data bits + CRC-8).  448 is the reference's own code (rtwm/polar_fast.py:8-9);
-        any other 16 <= K <= 1016 with K % 8 == 0 (PolarCode(1024, K), rtwm/fastpolar.py:209-234) makes an engine whose `scl` is the only
-        FEC entry point (rows of K/8 - 1 bytes), on the lane-per-path kernel: it needs list_size_max > 32 or the "scl_lane_slab" option.
+        any other 9 <= K <= 1024 (PolarCode(1024, K), rtwm/fastpolar.py:209-234) makes an engine whose `scl` is the only FEC entry point
+        (rows of ceil((K - 8) / 8) bytes = np.packbits of the information bits), on the lane-per-path kernel: it needs list_size_max > 32
+        or the "scl_lane_slab" option.
         list_size_max: the largest list `scl` will be asked for (sizes the list decoder's scratch: 0.4 GB, above 32 another 1.6 GB);
         0 = a front-end engine (everything but `scl`, no list-decoder scratch): what a pipeline's band-pass / sync / demodulator streams use."""
         if not torch.cuda.is_available():

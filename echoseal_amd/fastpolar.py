@@ -122,8 +122,8 @@ class PolarCode:
         llr = np.asarray(llr)
         if llr.ndim != 1 or llr.size != self.N:
             raise ValueError(f"llr must be 1D length {self.N}")
-        if self.N != 1024 or self.crc_size != 8 or self.K % 8 or not 16 <= self.K <= 1016:
-            raise NotImplementedError("the HIP decoder serves Polar(1024, K) + CRC-8 with K % 8 == 0 and 16 <= K <= 1016 (DESIGN.md section 7)")
+        if self.N != 1024 or self.crc_size != 8:
+            raise NotImplementedError("the HIP decoder serves Polar(1024, K) + CRC-8 (DESIGN.md section 7)")
         import torch
         from .engine import select_payload
         eng = engine_for(self.K)
@@ -133,4 +133,4 @@ class PolarCode:
         dev = torch.from_numpy(host).to(eng.device).reshape(1, self.N)
         res = eng.scl(dev, list_size=self.list_size, skip_if_hard_ok=(validator is None))
         payload, ok = select_payload(res, 0, validator)
-        return np.unpackbits(np.frombuffer(payload, dtype=np.uint8)), ok
+        return np.unpackbits(np.frombuffer(payload, dtype=np.uint8))[: self._info_len], ok

@@ -55,7 +55,7 @@ es_ctx*     es_create(int device, int list_size_max);
 void        es_destroy(es_ctx* ctx);
 const char* es_last_error(const es_ctx* ctx);          /* ctx may be NULL (creation errors) */
 int         es_abi_version(void);
-int         es_info_bytes(const es_ctx* ctx);          /* bytes of one packed information row of es_scl_batch: 55, or K/8 - 1 after es_set_tables with another K */
+int         es_info_bytes(const es_ctx* ctx);          /* bytes of one packed information row of es_scl_batch: 55, or ceil((K - 8) / 8) after es_set_tables with another K */
 
 /* Static per-band tables (host pointers).
  *   ba      [4][18]  Butterworth b[9] then a[9], float64      <- rtwm/utils.py:52-55 butter_bandpass
@@ -64,8 +64,9 @@ int         es_info_bytes(const es_ctx* ctx);          /* bytes of one packed in
  *   ntaps   [4]
  *   frozen  [1024]   1 = frozen bit                            <- rtwm/fastpolar.py:225-226
  * The mask leaves K information positions (information bits + CRC-8): 448 for the reference's own code (rtwm/polar_fast.py:8-9) and for
- * every entry point; es_scl_batch alone also serves any 16 <= K <= 1016 with K % 8 == 0 (what PolarCode(1024, K) of
- * rtwm/fastpolar.py:209-234 builds), with rows of es_info_bytes(ctx) = K/8 - 1 bytes in place of ES_INFO_BYTES.                 */
+ * every entry point; es_scl_batch alone also serves any 9 <= K <= 1024 (what PolarCode(1024, K) of rtwm/fastpolar.py:209-234
+ * builds), with rows of es_info_bytes(ctx) = ceil((K - 8) / 8) bytes in place of ES_INFO_BYTES: np.packbits of the K - 8
+ * information bits, i.e. zero padding in the last byte when K is not a multiple of 8.                                           */
 int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float* taps,
                   const int32_t* ntaps, const uint8_t* frozen);
 

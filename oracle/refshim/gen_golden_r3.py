@@ -3,7 +3,7 @@
 REFERENCE, captured by running it (build container only; /root/reference is read-only and never travels).  Only inputs
 and outputs are stored under tests/golden/ -- no reference source.
 
-    python -m oracle.refshim.gen_golden_r3 [all|inputs|sweep_default|sweep_glibc|codes]
+    python -m oracle.refshim.gen_golden_r3 [all|inputs|sweep_default|sweep_glibc|codes|codes2]
 
     polar_sweep_{default,glibc}.npz   for each L in (1, 4, 16): 256 LLR vectors through the reference's
         PolarCode.decode(list_size=L) (rtwm/fastpolar.py:254-359): (info, ok), whether the list loop ran, and the final
@@ -21,6 +21,8 @@ and outputs are stored under tests/golden/ -- no reference source.
         reference's PolarCode takes any K (rtwm/fastpolar.py:209-234); byte-aligned K is what rtwm/polar_fast.py can round-trip -- and
         L in (1, 8): six LLR vectors per K (codeword in light / heavy AWGN, garbage, +-12 ties on a codeword with flips, a clean
         codeword at +-3, zeros), (info, ok), whether the list loop ran, and the final list.
+    polar_codes2_{default,glibc}.npz  the same for K in (9, 13, 301, 1023, 1024): one information bit, K - 8 not a whole number of bytes
+        (rows are np.packbits of the information bits: zero padding), and a code without any frozen position.
 """
 from __future__ import annotations
 
@@ -158,10 +160,11 @@ def gen_sweep(mode, workers=6):
 
 
 CODES_K = (16, 64, 200, 512, 1000)
+CODES2_K = (9, 13, 301, 1023, 1024)        # K that is not a whole number of bytes; one information bit; no frozen position at all
 CODES_L = (1, 8)
 
 
-def gen_codes(mode):
+def gen_codes(mode, ks=CODES_K, name="polar_codes"):
     import builtins
     import numpy as np
     from oracle.refshim.shim import load_reference
@@ -176,8 +179,8 @@ def gen_codes(mode):
             captured["u"] = np.stack([p.u.copy() for p in out])
         return out
     fp.sorted = spy_sorted
-    out = {"meta_mode": np.array(mode), "meta_numpy": np.array(np.__version__), "ks": np.array(CODES_K), "lists": np.array(CODES_L)}
-    for K in CODES_K:
+    out = {"meta_mode": np.array(mode), "meta_numpy": np.array(np.__version__), "ks": np.array(ks), "lists": np.array(CODES_L)}
+    for K in ks:
         rng = np.random.default_rng(4000 + K)
         enc = fp.PolarCode(1024, K, list_size=1, crc_size=8)
         rows = []
@@ -216,7 +219,7 @@ def gen_codes(mode):
             out.update({f"{t}/info": info, f"{t}/ok": ok, f"{t}/took_list": took, f"{t}/cand_info": ci, f"{t}/cand_metric": cm,
                         f"{t}/cand_crc": cc, f"{t}/ncand": nc})
             print(f"  codes[{mode}] K={K} L={L}: ok {int(ok.sum())} list {int(took.sum())}", flush=True)
-    np.savez_compressed(os.path.join(GOLD, f"polar_codes_{mode}.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, f"{name}_{mode}.npz"), **out)
 
 
 def main():
@@ -236,6 +239,12 @@ def main():
         subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "codes_glibc"], cwd=ROOT, env=env)
     elif what in ("codes_default", "codes_glibc"):
         gen_codes(what.split("_")[1])
+    elif what == "codes2":
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "codes2_default"], cwd=ROOT, env=env)
+        env["NPY_DISABLE_CPU_FEATURES"] = AVX512_OFF
+        subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "codes2_glibc"], cwd=ROOT, env=env)
+    elif what in ("codes2_default", "codes2_glibc"):
+        gen_codes(what.split("_")[1], CODES2_K, "polar_codes2")
     elif what in ("sweep_default", "sweep_glibc"):
         gen_sweep(what.split("_")[1], workers=int(os.environ.get("GOLD_WORKERS", "6")))
     else:

@@ -209,12 +209,14 @@ def test_polar_sweep_matches_reference(oracle, mode, L):
     assert flips <= 2, flips
 
 
+@pytest.mark.parametrize("name", ["polar_codes", "polar_codes2"])
 @pytest.mark.parametrize("mode", ["default", "glibc"])
-def test_other_codes_match_reference(oracle, mode):
+def test_other_codes_match_reference(oracle, mode, name):
     """PolarCode(1024, K) for K other than the detector's 448 (the reference's class takes any K, rtwm/fastpolar.py:209-234): K = 16, 64, 200,
     512, 1000 at list sizes 1 and 8, six vectors each (clean, noisy, noise only, bit flips at +-12, constant magnitude, all zero) through the
-    reference's decode (oracle/refshim/gen_golden_r3.py codes)."""
-    g = _g(f"polar_codes_{mode}.npz"); gl = _g("polar_codes_glibc.npz")
+    reference's decode (oracle/refshim/gen_golden_r3.py codes); polar_codes2: K = 9, 13, 301, 1023, 1024 (one information bit; K - 8 not a whole
+    number of bytes -- rows are np.packbits of the information bits; no frozen position)."""
+    g = _g(f"{name}_{mode}.npz"); gl = _g(f"{name}_glibc.npz")
     listed = 0
     for K in g["ks"]:
         llrs = gl[f"K{K}/llr"].astype(np.float64)

@@ -137,15 +137,16 @@ def test_polar_sweep_vs_reference(engine, L):
         assert np.array_equal(ok.cpu().numpy() == 1, g[f"L{L}/ok"]), multi
 
 
-def test_other_codes_vs_reference():
-    """PolarCode(1024, K) for K = 16, 64, 200, 512, 1000 (the reference's class takes any K; its detector uses 448): the run-time-K
+@pytest.mark.parametrize("name", ["polar_codes", "polar_codes2"])
+def test_other_codes_vs_reference(name):
+    """PolarCode(1024, K) for K = 16, 64, 200, 512, 1000 and 9, 13, 301, 1023, 1024 (the reference's class takes any K; its detector uses 448): the run-time-K
     instantiation of the lane-per-path kernel against the reference's lists (C-library exp/log1p): bits, metrics and CRC flags identical, and
     (info, ok) through the host-side tail of PolarCode.decode."""
     from echoseal_amd.engine import RxEngine, select_payload
-    g = _g("polar_codes_glibc.npz")
+    g = _g(f"{name}_glibc.npz")
     for K in g["ks"]:
         eng = RxEngine(0, list_size_max=64, code_k=int(K))
-        assert eng.info_bytes == int(K) // 8 - 1
+        assert eng.info_bytes == (int(K) - 8 + 7) // 8
         llr, = _dev(eng, g[f"K{K}/llr"])
         for L in g["lists"]:
             t = f"K{K}/L{L}"

@@ -355,9 +355,10 @@ def test_scl_wide_lists_vs_oracle(oracle, L):
     eng.close()
 
 
-@pytest.mark.parametrize("K", [16, 24, 40, 64, 200, 440, 456, 512, 1000, 1016])
+@pytest.mark.parametrize("K", [9, 13, 16, 24, 40, 64, 200, 301, 440, 456, 512, 1000, 1016, 1023, 1024])
 def test_scl_other_codes_vs_oracle(oracle, K):
-    """Polar(1024, K) + CRC-8 for K other than 448 (whole bytes; a last trace-back window of 8, 16 or 24 bits; one or 32 windows): lists of every
+    """Polar(1024, K) + CRC-8 for K other than 448 (a last trace-back window of any length; one or 32 windows; K - 8 not a whole number of bytes;
+    one information bit; no frozen position): lists of every
     capacity against the oracle built for the same K, float32 and float64 LLRs, ragged batch sizes, and the API's PolarCode.decode."""
     from echoseal_amd.engine import RxEngine
     from rtwm.fastpolar import PolarCode
@@ -376,7 +377,7 @@ def test_scl_other_codes_vs_oracle(oracle, K):
             x = llr.astype(dt)[: (B if L <= 8 else 9)]
             res = eng.scl(torch.from_numpy(x).to(eng.device), list_size=L, skip_if_hard_ok=False).check()
             short = eng.scl(torch.from_numpy(x).to(eng.device), list_size=L, skip_if_hard_ok=True).check()
-            assert res.cand_info.shape[-1] == K // 8 - 1
+            assert res.cand_info.shape[-1] == (K - 8 + 7) // 8
             for i in range(x.shape[0]):
                 hinfo, hok = oracle.polar_hard(x[i].astype(np.float64))
                 assert np.packbits(hinfo).tobytes() == res.hard_info[i].cpu().numpy().tobytes() and hok == bool(res.hard_ok[i]), (L, i)
