@@ -234,13 +234,17 @@ __host__ __device__ __attribute__((noinline)) static double es_softplus_neg_gene
 ES_HD double es_softplus_neg_generic(double t, const uint64_t* tab) { return es_log1p(es_exp(t, tab)); }
 #endif
 
-/* Straight-line (branch-free) evaluation of the same value for the common range
- *     2^-54 <= |t| < 512  and  log1p not in its |f| < 2^-20 corner,
- * i.e. es_exp's main path followed by es_log1p's tiny / k==0 / k!=0 paths merged with selects.
+/* Straight-line (branch-free) evaluation of the same value for |t| < 512:
+ * es_exp's main path followed by es_log1p's tiny / k == 0 / k != 0 paths AND its |f| < 2^-20 corner, merged with selects.
  * Every arithmetic step is the one the generic functions perform for that input, so the result is
  * bit-identical; *ok = 0 flags inputs outside that range (caller falls back to the generic form).
  * Having no control flow lets the compiler interleave several independent evaluations, which is
- * what hides the ~1.3 k-cycle dependent latency of one evaluation on a single wavefront. */
+ * what hides the ~1.3 k-cycle dependent latency of one evaluation on a single wavefront.
+ * (ES_SOFTPLUS_CORNER 0 leaves the corner to the fall-back, as rounds 1-2 did: 2-17 % of the f evaluations from depth 5 down
+ * land in it -- more the weaker the signal --, so nearly every wave ran the generic form beside the straight-line one.) */
+#ifndef ES_SOFTPLUS_CORNER
+#define ES_SOFTPLUS_CORNER 1
+#endif
 ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
 {
     /* ---- exp(t), main path of es_exp ---- */
@@ -303,14 +307,26 @@ ES_HD double es_softplus_neg_fast(double t, const uint64_t* tab, int* ok)
     const double res0 = f - (hfsq - sR);
     const double resk = ES_LN2_HI - ((hfsq - (sR + (ES_LN2_LO + c))) - f);
     double res = k0 ? res0 : resk;
+#if ES_SOFTPLUS_CORNER
+    /* fdlibm's |f| < 2^-20 corner, which with k == 1 is u within 3 * 2^-20 below 2 (the fraction field of its high word >= 0xffffd), i.e.
+       1.1e-16 < |t| < 2.86e-6: differences and sums of LLRs a few f levels down the tree are that small all the time (f(x, y) ~ x*y/2 for
+       small operands), so the corner is part of the straight-line form, not of the fall-back.  f != 0 there (u < 2). */
+    const double Rc = hfsq * (1.0 - 0.66666666666666666 * f);
+    const double resc = ES_LN2_HI - ((Rc - (ES_LN2_LO + c)) - f);
+    res = ((uint32_t)(hu0 - 0x3FFFFFFDu) < 3u) ? resc : res;
+#endif
     const double rt = y - y * y * 0.5;
     res = tiny29 ? rt : res;
     /* Range of the straight-line form.  exp: every |t| < 512 -- below 2^-54 (in practice t == 0, which two LLRs clipped
      * to the same +-12 produce all the time) the main path yields exactly the 1.0 that es_exp's early return (1 + t)
      * rounds to.  log1p: its |f| < 2^-20 corner (fdlibm's hu == 0: for k == 1 the fraction field of u's high word is >= 0xffffd,
-     * i.e. the high word is 0x3ffffffd..0x3fffffff) is left to the generic form; at u == 2 (y == 1, that t == 0 case; high word
+     * i.e. the high word is 0x3ffffffd..0x3fffffff) is the select above; at u == 2 (y == 1, that t == 0 case; high word
      * 0x40000000) f == 0 and fdlibm's shortcut  k*ln2_hi + (c + k*ln2_lo)  is what resk evaluates to term by term. */
+#if ES_SOFTPLUS_CORNER
+    *ok = (__builtin_fabs(t) < 512.0);
+#else
     *ok = (__builtin_fabs(t) < 512.0) && ((uint32_t)(hu0 - 0x3FFFFFFDu) >= 3u);
+#endif
     return res;
 }
 

@@ -582,8 +582,7 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                         // three operand pairs in rotation, the loop unrolled by three so that the rotation is a renaming, not a copy (a copy of a
                         // register that a load is still filling waits for the load): the operands of element j + 3 are requested right after
                         // f(j) and used two f evaluations later.  Loads past the end re-read the last element (S >= 8).
-                        // The loop body is straight-line: operands outside the range of the straight-line softplus (|t| >= 512, or 1 + e^t within
-                        // 3 * 2^-20 below 2) only raise `bad`, and the level is then redone with the generic form in a cold loop after it.
+                        // The loop body is straight-line: operands outside the range of the straight-line softplus (|t| >= 512) only raise `bad`, and the level is then redone with the generic form in a cold loop after it.
 #if ES_WIDE_DEFER & 1
                         double a0, b0_, a1, b1_, a2, b2_;
                         int bad = 0;

@@ -815,9 +815,9 @@ def test_scl_multi_frames_per_wave(engine, oracle, L):
 @pytest.mark.parametrize("L", [1, 8, 32])
 def test_scl_softplus_fallback_ranges(engine, oracle, L):
     """Operands that leave the straight-line softplus of the list decoders: |t| >= 512 (sums of many +-12 LLRs, float64 LLRs of
-    magnitude up to 400 -- exp underflows to subnormals and to zero), and 1 + e^t within 3 * 2^-20 below 2 (operands that differ by
-    ~1e-7: fdlibm's |f| < 2^-20 corner).  The hot loops only flag such lanes and redo the evaluation with the generic form outside
-    the loop; every mapping must still equal the oracle bit for bit."""
+    magnitude up to 400 -- exp underflows to subnormals and to zero): the hot loops only flag such lanes and redo the evaluation with
+    the generic form outside the loop.  And 1 + e^t within 3 * 2^-20 below 2 (operands that differ by ~1e-7: fdlibm's |f| < 2^-20 corner,
+    a select inside the straight-line form since round 3).  Every mapping must equal the oracle bit for bit."""
     rng = np.random.default_rng(900 + L)
     rows = []
     for k in range(24):
@@ -1063,6 +1063,8 @@ def test_device_softplus_bits(engine, oracle):
         -np.abs(rng.normal(0, 6, 1_000_000)), -rng.uniform(0, 1.0, 500_000), -rng.uniform(0.85, 0.92, 200_000),
         -rng.uniform(15, 45, 300_000), -rng.uniform(0, 800, 300_000), -np.abs(rng.normal(0, 3000, 200_000)),
         -np.ldexp(rng.uniform(0.5, 1, 300_000), -rng.integers(0, 80, 300_000)),
+        -(10.0 ** rng.uniform(-18, -4, 300_000)), -(2.86e-6 + rng.uniform(-1e-7, 1e-7, 50_000)),      # fdlibm's |f| < 2^-20 corner of log1p (a select
+        -(1.1e-16 + rng.uniform(-1e-16, 2e-16, 50_000)),                                                #  in the straight-line form) and both its edges
         -np.arange(0, 24.0, 1.0 / 8192),                                            # a regular grid (clipped-LLR differences)
         np.array([0.0, -0.0, -0.8813735870195429, -0.881373587019543, -0.8813735870195432, -20.1, -20.101268236238414,
                   -37.42994775023705, -37.5, -511.9, -512.0, -745.2, -1e-300, -2.0 ** -54, -2.0 ** -55, -np.inf])])

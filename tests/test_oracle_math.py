@@ -79,3 +79,23 @@ def test_softplus_of_exact_zero(oracle):
             assert _bits(np.array([got]))[0] == _bits(np.array([np.float64(ref)]))[0]
     a = np.array([12.0, -12.0, 3.5, 0.0]); b = np.array([12.0, 12.0, -3.5, 0.0])
     assert np.array_equal(_bits(oracle.polar_f_vec(a, b)), _bits(np.logaddexp(a, b) - np.logaddexp(0.0, a + b)))
+
+
+def test_softplus_in_the_log1p_corner(oracle):
+    """|t| between 1.1e-16 and 2.86e-6 puts 1 + exp(t) within 3 * 2^-20 below 2, where fdlibm's log1p takes its |f| < 2^-20 form.
+    Operands a few f levels down the tree differ (and sum) by that little all the time (f(x, y) ~ x*y/2 for small x, y), so the straight-line
+    softplus of es_math.h carries that form as a select (round 3; before, it was left to the generic fall-back): both edges of the corner,
+    its inside on a log scale, and what lies below it, against libm and against NumPy's logaddexp formula, bit for bit."""
+    m = _libm()
+    rng = np.random.default_rng(15)
+    mags = np.concatenate([10.0 ** rng.uniform(-18, -4, 200_000),
+                           2.86e-6 + rng.uniform(-1e-7, 1e-7, 50_000),         # the upper edge (u's high word 0x3ffffffc | 0x3ffffffd)
+                           1.1e-16 + rng.uniform(-1e-16, 2e-16, 50_000)])      # the lower edge (exp(t) rounds to 1.0 below it)
+    for bit in (0, 1):
+        got = oracle.penalty_vec(mags, bit)                                     # l >= 0: log1p(exp(-l)) (+ l when the bit disagrees)
+        pen = np.array([m.log1p(m.exp(-x)) for x in mags[:60_000]])
+        ref = pen + mags[:60_000] if bit == 0 else pen
+        assert np.array_equal(_bits(got[:60_000]), _bits(ref))
+    base = np.clip(rng.normal(0, 2, mags.size), -12, 12)
+    for a, b in ((base, base + mags), (base, -base + mags), (mags, mags * rng.uniform(0, 2, mags.size)), (mags, np.zeros_like(mags))):
+        assert np.array_equal(_bits(oracle.polar_f_vec(a, b)), _bits(np.logaddexp(a, b) - np.logaddexp(0.0, a + b)))

@@ -12,7 +12,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         nat.LIB_PATH = os.path.join(os.path.dirname(nat.LIB_PATH), f"libechoseal_hip_{name}.so")
     from echoseal_amd.engine import RxEngine
     eng = RxEngine(0, list_size_max=256); rng = np.random.default_rng(0)
-    base = torch.from_numpy(np.clip(rng.normal(0, 3, (4096, 1024)), -12, 12).astype(np.float32)).to(eng.device)
+    sigma = float(os.environ.get("ES_AB_SIGMA", "3")); zero = float(os.environ.get("ES_AB_ZERO", "0"))   # LLR scale; share of exact zeros (weak / cut frames)
+    x = np.clip(rng.normal(0, sigma, (4096, 1024)), -12, 12).astype(np.float32)
+    if zero: x[rng.random(x.shape) < zero] = 0.0
+    base = torch.from_numpy(x).to(eng.device)
     base[::7] = torch.round(base[::7])                                   # some tie-heavy rows
     eng.set_option("scl_multi", 1); eng.set_option("scl_lanes", 1)
     for L, B in ((8, 65536), (8, 24576), (32, 8192), (256, 1024)):
