@@ -44,6 +44,20 @@ int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_
     return ES_OK;
 }
 
+int es_compact_reserve(es_ctx* ctx, int64_t B, hipStream_t st)
+{
+    if (B > ctx->compact_cap) {
+        // first use, or a larger batch than any before (es_reserve sizes it ahead): allocation synchronises, which a capture cannot do
+        if (capturing(st)) { ctx->err = "es_scl_batch: the frame list of this batch size has not been allocated yet -- run the call once outside the capture, or es_reserve(B_max, ...)"; return ES_EINVAL; }
+        if (ctx->d_compact) ES_HIP_CHECK(ctx, hipFree(ctx->d_compact));            // (hipFree waits for the device: nothing still reads it)
+        ctx->d_compact = nullptr; ctx->compact_cap = 0;
+        const int64_t cap = B < 65536 ? 65536 : B;
+        if (hipMalloc(&ctx->d_compact, (size_t)(cap + 16) * sizeof(int32_t)) != hipSuccess) { ctx->err = "es_scl_batch: device allocation of the frame list failed"; return ES_ENOMEM; }
+        ctx->compact_cap = cap;
+    }
+    return es_slab_enter(ctx, 2, 0, false, st);                                      // one list per context: launches on another stream drain first
+}
+
 extern "C" {
 
 int es_abi_version(void) { return 1; }
@@ -120,6 +134,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_wide_slot_bits) (void)hipFree(ctx->d_wide_slot_bits);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
     if (ctx->d_hdr_pn) (void)hipFree(ctx->d_hdr_pn);
+    if (ctx->d_compact) (void)hipFree(ctx->d_compact);
     delete ctx;
 }
 
@@ -277,6 +292,10 @@ int es_reserve(es_ctx* ctx, int64_t B_max, int T_max)
         ctx->d_ws_corr = nullptr; ctx->ws_corr_bytes = 0;
         if (hipMalloc(&ctx->d_ws_corr, need) != hipSuccess) return fail(ctx, ES_ENOMEM, "es_reserve: device allocation of the float64 correlation workspace failed");
         ctx->ws_corr_bytes = need;
+    }
+    if (ctx->d_wide_scratch && B_max > ctx->compact_cap) {                            // the list decoder's frame list (compacted launches)
+        const int rc = es_compact_reserve(ctx, B_max, nullptr);
+        if (rc) return rc;
     }
     return ES_OK;
 }

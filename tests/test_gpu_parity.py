@@ -812,6 +812,40 @@ def test_scl_multi_frames_per_wave(engine, oracle, L):
         assert np.array_equal(cc[:nn], got.cand_ok[i, :nn].cpu().numpy())
 
 
+@pytest.mark.parametrize("L", [2, 8, 24, 64, 256])
+def test_scl_compacted_launch(L):
+    """skip_if_hard_ok on the lane-per-path kernel: the hard-decision shortcut runs for every frame first, a one-block scan lists the frames
+    that failed it and the list kernel decodes only those (a wave would otherwise carry the settled frames along as idle lanes).  Frames
+    that pass and frames that do not, mixed at random / all / none, ragged batch sizes: the rows of the listed frames equal an uncompacted
+    launch's, the settled frames read ncand = 0 and zero rows, hard_info / hard_ok are the same."""
+    from echoseal_amd.engine import RxEngine
+    eng = RxEngine(0, list_size_max=256)
+    eng.set_option("scl_multi", 1); eng.set_option("scl_lanes", 1)
+    rng = np.random.default_rng(40 + L)
+    info = rng.integers(0, 256, (600, 55), dtype=np.uint8)
+    code = eng.polar_encode(torch.from_numpy(info).to(eng.device)).cpu().numpy().astype(np.float64)
+    clean = (2.0 * code - 1.0) * 6.0                                                  # passes the hard decision
+    noisy = np.clip(2.0 * (2.0 * code - 1.0 + rng.normal(0, 1.0, code.shape)), -12, 12)   # does not
+    for B, share in ((1, 0.0), (1, 1.0), (7, 0.5), (8, 0.5), (9, 0.9), (65, 0.0), (130, 1.0), (600, 0.3), (600, 0.97)):
+        if L > 64 and B > 130:
+            continue
+        pick = rng.random(B) < share
+        x = np.where(pick[:, None], noisy[:B], clean[:B]).astype(np.float32)
+        t = torch.from_numpy(x).to(eng.device)
+        full = eng.scl(t, list_size=L, skip_if_hard_ok=False).check()
+        comp = eng.scl(t, list_size=L, skip_if_hard_ok=True).check()
+        assert torch.equal(full.hard_info, comp.hard_info) and torch.equal(full.hard_ok, comp.hard_ok), (B, share)
+        hok = full.hard_ok.cpu().numpy().astype(bool)
+        assert np.array_equal(hok, ~pick) or share in (0.5, 0.9, 0.3, 0.97), (B, share)     # (a noisy frame may pass by luck)
+        took = torch.from_numpy(~hok).to(eng.device)
+        assert torch.equal(comp.ncand[~took], torch.zeros_like(comp.ncand[~took])) and torch.equal(comp.ncand[took], full.ncand[took]), (B, share)
+        for name in ("cand_info", "cand_metric", "cand_ok"):
+            a, c = getattr(full, name), getattr(comp, name)
+            assert torch.equal(a[took], c[took]), (name, B, share)
+            assert not bool(c[~took].to(torch.float64).abs().sum().item()), (name, B, share)
+    eng.close()
+
+
 @pytest.mark.parametrize("L", [1, 8, 32])
 def test_scl_softplus_fallback_ranges(engine, oracle, L):
     """Operands that leave the straight-line softplus of the list decoders: |t| >= 512 (sums of many +-12 LLRs, float64 LLRs of
