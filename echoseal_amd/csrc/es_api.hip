@@ -44,18 +44,12 @@ int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_
     return ES_OK;
 }
 
-int es_compact_reserve(es_ctx* ctx, int64_t B, hipStream_t st)
+// A launch that draws its frames from a counter gets a counter of its own: launches of one context on several streams (or in several
+// captured graphs) never share one unless ES_CURSOR_RING of them are in flight at once.
+int es_cursor_next(es_ctx* ctx, int** cursor)
 {
-    if (B > ctx->compact_cap) {
-        // first use, or a larger batch than any before (es_reserve sizes it ahead): allocation synchronises, which a capture cannot do
-        if (capturing(st)) { ctx->err = "es_scl_batch: the frame list of this batch size has not been allocated yet -- run the call once outside the capture, or es_reserve(B_max, ...)"; return ES_EINVAL; }
-        if (ctx->d_compact) ES_HIP_CHECK(ctx, hipFree(ctx->d_compact));            // (hipFree waits for the device: nothing still reads it)
-        ctx->d_compact = nullptr; ctx->compact_cap = 0;
-        const int64_t cap = B < 65536 ? 65536 : B;
-        if (hipMalloc(&ctx->d_compact, (size_t)(cap + 16) * sizeof(int32_t)) != hipSuccess) { ctx->err = "es_scl_batch: device allocation of the frame list failed"; return ES_ENOMEM; }
-        ctx->compact_cap = cap;
-    }
-    return es_slab_enter(ctx, 2, 0, false, st);                                      // one list per context: launches on another stream drain first
+    *cursor = ctx->d_cursors + (ctx->cursor_next++ % ES_CURSOR_RING);
+    return ES_OK;
 }
 
 extern "C" {
@@ -111,6 +105,11 @@ es_ctx* es_create(int device, int list_size_max)
         es_destroy(ctx);
         return nullptr;
     }
+    if (hipMalloc(&ctx->d_cursors, ES_CURSOR_RING * sizeof(int)) != hipSuccess || hipMemset(ctx->d_cursors, 0, ES_CURSOR_RING * sizeof(int)) != hipSuccess) {
+        g_create_err = "device allocation of the frame counters failed";
+        es_destroy(ctx);
+        return nullptr;
+    }
     if (ctx->wide_scratch_bytes && hipMalloc(&ctx->d_wide_scratch, ctx->wide_scratch_bytes) != hipSuccess) {
         g_create_err = "device allocation of the wide-list SCL scratch slab failed";
         ctx->d_wide_scratch = nullptr;
@@ -134,7 +133,7 @@ void es_destroy(es_ctx* ctx)
     if (ctx->d_wide_slot_bits) (void)hipFree(ctx->d_wide_slot_bits);
     if (ctx->d_sbox) (void)hipFree(ctx->d_sbox);
     if (ctx->d_hdr_pn) (void)hipFree(ctx->d_hdr_pn);
-    if (ctx->d_compact) (void)hipFree(ctx->d_compact);
+    if (ctx->d_cursors) (void)hipFree(ctx->d_cursors);
     delete ctx;
 }
 
@@ -292,10 +291,6 @@ int es_reserve(es_ctx* ctx, int64_t B_max, int T_max)
         ctx->d_ws_corr = nullptr; ctx->ws_corr_bytes = 0;
         if (hipMalloc(&ctx->d_ws_corr, need) != hipSuccess) return fail(ctx, ES_ENOMEM, "es_reserve: device allocation of the float64 correlation workspace failed");
         ctx->ws_corr_bytes = need;
-    }
-    if (ctx->d_wide_scratch && B_max > ctx->compact_cap) {                            // the list decoder's frame list (compacted launches)
-        const int rc = es_compact_reserve(ctx, B_max, nullptr);
-        if (rc) return rc;
     }
     return ES_OK;
 }

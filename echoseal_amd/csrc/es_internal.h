@@ -47,9 +47,9 @@ struct es_ctx {
        domain 1 = d_wide_scratch (es_scl_wide.hip).  `shape`: how the launch cuts the slab into slots; launches of one shareable shape on
        several streams share the slab through its slot bitmap, anything else is ordered behind the outstanding launches. */
     struct slab_use { int shape = -1; bool shareable = false; std::vector<hipStream_t> streams; };   /* streams that have launched with `shape` */
-    slab_use slab[3];                 /* (domain 2 = d_compact, never shareable) */
-    int32_t* d_compact = nullptr;     /* compacted launches of the lane-per-path list decoder: [0] the count, [16 ..] the frames that failed the hard decision */
-    int64_t compact_cap = 0;
+    slab_use slab[2];
+    int* d_cursors = nullptr;         /* frame counters of the lane-per-path list decoder's launches (skip_if_hard_ok): a ring, one per launch */
+    unsigned cursor_next = 0;
     bool pick_attr_set = false;       /* per-device kernel attributes already raised for this context's device */
     unsigned wide_attr_mask = 0;      /* bit per instantiation of the lane-per-path list decoder (its list capacity 1 .. 256) */
     /* tuning (es_set_option) */
@@ -81,7 +81,8 @@ int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_
 size_t es_scl_scratch_bytes(const es_ctx* ctx);
 size_t es_scl_wide_scratch_bytes(const es_ctx* ctx, int* slots_out);
 size_t es_scl_multi_scratch_bytes(const es_ctx* ctx);
-int es_compact_reserve(es_ctx* ctx, int64_t B, hipStream_t st);   /* d_compact for B frames, ordered behind its other users (es_api.hip) */
+#define ES_CURSOR_RING 1024
+int es_cursor_next(es_ctx* ctx, int** cursor);                   /* the next counter of the ring (es_api.hip) */
 int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
                         uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
                         uint8_t* cand_ok, int32_t* ncand, hipStream_t st);

@@ -54,7 +54,7 @@
 #define ES_WIDE_DEFER 12                          /* where the generic softplus is a deferred cold path instead of a branch after each evaluation: 1 slab f loops, 2 depth 8, 4 depth 9, 8 depth 10 */
 #endif
 #ifndef ES_WIDE_COMPACT
-#define ES_WIDE_COMPACT 1                         /* skip_if_hard_ok: hard decisions of all frames first, the list kernel on the frames that failed it (0: inside the list kernel, settled frames ride along) */
+#define ES_WIDE_COMPACT 1                         /* skip_if_hard_ok: blocks draw frames from a counter until they hold a full group that failed the hard decision (0: fixed groups, settled frames ride along as idle lanes) */
 #endif
 #ifndef ES_WIDE_FDIST
 #define ES_WIDE_FDIST 2                           /* f loops: operand pairs requested this many f evaluations ahead (1: rotation by copy; 2: unrolled by three) */
@@ -74,8 +74,8 @@ struct WideArgs {
     int skip_if_hard_ok;
     int lsz;                                  // the caller's list size (<= L)
     unsigned* slot_bits; int n_slots, slot_words;   // bitmap of slab slots (one per resident block), as in es_scl_multi.hip
-    const int32_t* active;                    // null: every frame, in order.  Else the frames that go through the list loop (es_active_list_kernel):
-    const int32_t* n_active;                  //   n_active[0] of them, ascending; the hard decision of all B frames is already in hard_info / hard_ok
+    int* cursor;                              // null: block g decodes frames [g * FRG, (g + 1) * FRG).  Else (skip_if_hard_ok) blocks draw frames from this counter
+                                              //   (zeroed before the launch) until they hold FRG that failed the hard decision: settled frames never ride along
     int n_info, info_bytes;                   // GK instantiations: data bits K (information + CRC) and bytes of a packed information row, ceil((K - 8) / 8)
     int prio;                                 // wave priority 0..3 (es_set_option "scl_prio"): a later launch of a burst may overtake an earlier one
 };
@@ -99,6 +99,7 @@ struct WideLds {
     uint32_t xhist[NB][L];              // ... bits of the current trace-back window
     uint32_t betaM[3][L];               // partial-sum blocks of 32 (row 0) and 64 bits (1, 2), by slot (wider ones, touched a few times per frame: slab)
     uint16_t sidx[NB][2 * L];
+    int      fr[64];                    // frames drawn from the cursor (up to 64 per one-wave block)
     int      flag;
     // (the hard decision's 184 bytes borrow the first wave's cells of skey[0])
 };
@@ -365,8 +366,6 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     WideLds<L, NB>& W = *reinterpret_cast<WideLds<L, NB>*>(smem_raw);
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio >= 3) __builtin_amdgcn_s_setprio(3);
-    const long long nfr = a.active ? (long long)a.n_active[0] : a.B;       // frames this launch decodes (block-uniform)
-    if ((long long)blockIdx.x * FRG >= nfr) return;                          // a launch is sized for B frames: the blocks past the active ones leave at once
     const int p = threadIdx.x;                       // slot == lane of the block
     const int lane = p & 63, wv = p >> 6;
     const int pl = p % LF;                           // path within its frame
@@ -384,7 +383,9 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
     if (p == 0) {
         int slot = -1;
         unsigned w = blockIdx.x % (unsigned)a.slot_words;
-        for (int tries = 0; slot < 0 && tries < (1 << 22); ++tries) {
+        const bool drained = a.cursor && __hip_atomic_load(a.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.B;   // (a launch is sized for B frames: blocks that come after the last frame was drawn leave at once)
+        if (drained) slot = -2;
+        for (int tries = 0; slot == -1 && tries < (1 << 22); ++tries) {
             const unsigned v = __hip_atomic_load(&a.slot_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned valid = (w == (unsigned)a.slot_words - 1 && (a.n_slots & 31)) ? ((1u << (a.n_slots & 31)) - 1u) : 0xffffffffu;
             const unsigned freeb = ~v & valid;
@@ -402,9 +403,11 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
     __syncthreads();
     const int slot = W.flag;
     __syncthreads();
+    if (slot == -2) return;
     if (slot < 0) {                                                    // cannot happen (see the launcher); never spin forever, never fail silently:
         constexpr int FRB = FRG;                                        // the block's frames read ncand = -1
-        for (long long ff = (long long)blockIdx.x * FRB + p; p < FRB && ff < nfr; ff += nfr) a.ncand[a.active ? a.active[ff] : ff] = -1;
+        if (a.cursor) { if (p < FRB) { const long long ff = atomicAdd(a.cursor, 1); if (ff < a.B) a.ncand[ff] = -1; } }
+        else for (long long ff = (long long)blockIdx.x * FRB + p; p < FRB && ff < a.B; ff += a.B) a.ncand[ff] = -1;
         return;
     }
     double* const A = a.alpha + (long long)slot * N * L;             // element e of slot s at A[e*L + s]
@@ -420,22 +423,62 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
 
     uint32_t* const hd_words = reinterpret_cast<uint32_t*>(&W.skey[0][0]);                  // 32 words ...
     uint8_t* const hd_bytes = reinterpret_cast<uint8_t*>(&W.skey[0][16]);                   // ... and 56 bytes of the hard decision (first wave)
-    const long long n_groups = (nfr + FRG - 1) / FRG;
+    const long long n_groups = a.cursor ? (long long)gridDim.x : (a.B + FRG - 1) / FRG;      // (cursor: one draw per block)
     for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {      // one group of FRG frames per block (grid = groups)
+        long long f; bool f_valid;
+        uint64_t active_mask = 0;                              // block-uniform: frames that go through the list loop (up to 64 of them)
+        if (a.cursor) {
+            // ---------------- draw frames until FRG of them fail the hard decision (fastpolar.py:260-268) or none are left
+            if constexpr (WAVE) {
+                int n = 0;
+                while (n < FRG) {
+                    int ff = 0;
+                    if (lane == 0) ff = atomicAdd(a.cursor, 1);
+                    ff = __shfl(ff, 0);
+                    if (ff >= a.B) break;
+                    const int ok = hard_decision_wave<GK>(a, ff, lane, hd_words, hd_bytes, a.data_pos);
+                    if (ok) {                                  // settled: its candidate rows read as zeros
+                        if (lane == 0) a.ncand[ff] = 0;
+                        #pragma unroll 1
+                        for (int k = lane; k < a.lsz * NIB; k += 64) a.cand_info[(long long)ff * a.lsz * NIB + k] = 0;
+                        #pragma unroll 1
+                        for (int k = lane; k < a.lsz; k += 64) { a.cand_metric[(long long)ff * a.lsz + k] = 0.0; a.cand_ok[(long long)ff * a.lsz + k] = 0; }
+                    } else { if (lane == 0) W.fr[n] = ff; ++n; }
+                }
+                wave_fence_lds();
+                if (n == 0) break;
+                f_valid = (lane / LF) < n;
+                f = W.fr[f_valid ? lane / LF : 0];             // a missing frame mirrors the first one (never stored)
+                active_mask = (n >= 64) ? ~0ULL : ((1ULL << n) - 1ULL);
+            } else {
+                int ff;
+                for (;;) {
+                    if (p == 0) W.fr[0] = atomicAdd(a.cursor, 1);
+                    __syncthreads();
+                    ff = W.fr[0];
+                    if (ff >= a.B) break;
+                    if (wv == 0) {
+                        const int ok = hard_decision_wave<GK>(a, ff, lane, hd_words, hd_bytes, a.data_pos);
+                        if (lane == 0) W.flag = ok;
+                    }
+                    __syncthreads();
+                    const int ok = W.flag;
+                    __syncthreads();
+                    if (!ok) break;
+                    if (p == 0) a.ncand[ff] = 0;
+                    for (int k = p; k < a.lsz * NIB; k += L) a.cand_info[(long long)ff * a.lsz * NIB + k] = 0;
+                    if (p < a.lsz) { a.cand_metric[(long long)ff * a.lsz + p] = 0.0; a.cand_ok[(long long)ff * a.lsz + p] = 0; }
+                }
+                if (ff >= a.B) break;
+                f = ff; f_valid = true; active_mask = 1ULL;
+            }
+        } else {
         const long long f_raw = g * FRG + (WAVE ? lane / LF : 0);
-        const bool f_valid = f_raw < nfr;
-        const long long f_pos = f_valid ? f_raw : nfr - 1;      // a missing frame mirrors the last one (never stored)
-        const long long f = a.active ? (long long)a.active[f_pos] : f_pos;
-        const float* llr32 = (const float*)a.llr + f * N;
-        const double* llr64 = (const double*)a.llr + f * N;
+        f_valid = f_raw < a.B;
+        f = f_valid ? f_raw : a.B - 1;          // a missing frame mirrors the last one (never stored)
 
         // ---------------- hard decision (fastpolar.py:260-268): frame by frame, one wave each
-        uint64_t active_mask = 0;                              // block-uniform: frames that go through the list loop (up to 64 of them)
-        if (a.active) {                                        // compacted launch: hard decisions and the rows of the skipped frames are done
-            const long long nv = nfr - g * FRG;
-            active_mask = (nv >= 64) ? ~0ULL : ((1ULL << nv) - 1ULL);
-            if (FRG < 64) active_mask &= (1ULL << FRG) - 1ULL;
-        } else if constexpr (WAVE) {
+        if constexpr (WAVE) {
             for (int fi = 0; fi < FRG; ++fi) {
                 const long long ff = g * FRG + fi;
                 if (ff >= a.B) break;
@@ -461,6 +504,9 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
             } else active_mask = 1ULL;
             __syncthreads();
         }
+        }
+        const float* llr32 = (const float*)a.llr + f * N;
+        const double* llr64 = (const double*)a.llr + f * N;
         if (active_mask == 0) continue;
         const bool f_store = f_valid && ((active_mask >> (WAVE ? lane / LF : 0)) & 1ULL);
 
@@ -872,54 +918,6 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
 }
 
 
-// ---- compacted launches (skip_if_hard_ok): the hard decision of every frame first, then the list of the frames that failed it -----------
-// A wave of the list kernel carries 64 / LF frames through the whole decode in lock step; a frame that passes the hard-decision shortcut
-// (fastpolar.py:260-268) would ride along as idle lanes.  So the shortcut runs first, for all B frames (one wave per frame: hard_info, hard_ok,
-// zero candidate rows for the frames it settles), a one-block scan lists the others in ascending order, and the list kernel decodes
-// list[0 .. n) -- a launch sized for B whose blocks past ceil(n / frames per block) leave at once.
-template <bool GK>
-__global__ __launch_bounds__(256) void es_hard_kernel(WideArgs a)
-{
-    __shared__ uint32_t s_words[4][32];
-    __shared__ uint8_t s_bytes[4][128];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int NIB = GK ? a.info_bytes : ES_INFO_BYTES;
-    for (long long f = (long long)blockIdx.x * 4 + wv; f < a.B; f += (long long)gridDim.x * 4) {
-        const int ok = hard_decision_wave<GK>(a, f, lane, s_words[wv], s_bytes[wv], a.data_pos);
-        if (ok) {                                              // settled here: its candidate rows read as zeros
-            if (lane == 0) a.ncand[f] = 0;
-            for (int k = lane; k < a.lsz * NIB; k += 64) a.cand_info[f * a.lsz * NIB + k] = 0;
-            for (int k = lane; k < a.lsz; k += 64) { a.cand_metric[f * a.lsz + k] = 0.0; a.cand_ok[f * a.lsz + k] = 0; }
-        }
-    }
-}
-
-__global__ __launch_bounds__(1024) void es_active_list_kernel(const uint8_t* hard_ok, long long B, int32_t* n_active, int32_t* list)
-{
-    // wave w owns the frames [w * seg, (w + 1) * seg), 64 at a time (coalesced byte loads, several in flight; a ballot gives the positions)
-    __shared__ int s_wave[16];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const long long seg = ((B + 15) / 16 + 63) / 64 * 64;
-    const long long lo = wv * seg < B ? wv * seg : B, hi = lo + seg < B ? lo + seg : B;
-    int cnt = 0;
-    for (long long f0 = lo; f0 < hi; f0 += 64) {
-        const long long f = f0 + lane;
-        cnt += __popcll(__ballot(f < hi && !hard_ok[f]));
-    }
-    if (lane == 0) s_wave[wv] = cnt;
-    __syncthreads();
-    int pos = 0, total = 0;
-    for (int w = 0; w < 16; ++w) { const int c = s_wave[w]; if (w < wv) pos += c; total += c; }
-    for (long long f0 = lo; f0 < hi; f0 += 64) {
-        const long long f = f0 + lane;
-        const bool act = f < hi && !hard_ok[f];
-        const unsigned long long m = __ballot(act);
-        if (act) list[pos + __popcll(m & ((1ULL << lane) - 1ULL))] = (int32_t)f;
-        pos += __popcll(m);
-    }
-    if (t == 0) n_active[0] = total;
-}
-
 template <int L, int LF, bool GK = false>
 int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
 {
@@ -979,17 +977,11 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
     a.lsz = L;
     a.prio = ctx->scl_prio;
     a.n_info = ctx->n_info; a.info_bytes = (ctx->n_info - 8 + 7) / 8;
-    if (skip_if_hard_ok && ES_WIDE_COMPACT) {             // the shortcut for all frames first, then the list of the others (see es_hard_kernel)
-        if (B >= (1LL << 31) - 1024) { ctx->err = "es_scl_batch: batch too large for one launch"; return ES_EINVAL; }
-        const int rc = es_compact_reserve(ctx, B, st);
+    if (skip_if_hard_ok && ES_WIDE_COMPACT) {             // frames drawn from a counter: see the kernel (settled frames never ride along as idle lanes)
+        if (B >= (1LL << 31) - (1LL << 24)) { ctx->err = "es_scl_batch: batch too large for one launch"; return ES_EINVAL; }   // (the counter runs past B by one draw per block)
+        const int rc = es_cursor_next(ctx, &a.cursor);
         if (rc) return rc;
-        long long hb = (B + 3) / 4; if (hb > 8LL * ctx->num_cu * 4) hb = 8LL * ctx->num_cu * 4;
-        if (ctx->n_info != KINFO) hipLaunchKernelGGL(es_hard_kernel<true>, dim3((unsigned)hb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(es_hard_kernel<false>, dim3((unsigned)hb), dim3(256), 0, st, a);
-        ES_HIP_CHECK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(es_active_list_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)hard_ok, (long long)B, ctx->d_compact, ctx->d_compact + 16);
-        ES_HIP_CHECK(ctx, hipGetLastError());
-        a.n_active = ctx->d_compact; a.active = ctx->d_compact + 16;
+        ES_HIP_CHECK(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int), st));
     }
     int LP = 1; while (LP < L) LP <<= 1;                  // kernel capacity: the next power of two
     if (ctx->n_info != KINFO) switch (LP) {               // a code other than the reference's own K = 448: the run-time-K instantiations
