@@ -178,7 +178,9 @@ int es_header_batch(es_ctx* ctx, const double* y_dev, int64_t B, int T, const in
  *   list_size       1..256 (<= the context's list_size_max); any size, as in the reference: a size that is not a power of
  *                   two runs on the next power of two's kernel with the surplus paths switched off
  *   skip_if_hard_ok non-zero: records whose hard decision passes CRC skip the list loop
- *                   (the reference's behaviour when validator is None, fastpolar.py:268-276)
+ *                   (the reference's behaviour when validator is None, fastpolar.py:268-276); the lane-per-path kernel then
+ *                   fills its waves with the records that do not pass (drawn from a per-launch counter), so a batch of
+ *                   mostly clean records costs what its noisy ones cost
  *   hard_info_dev   [B][55], hard_ok_dev [B]
  *   cand_info_dev   [B][L][55] candidates in ascending path-metric (stable) order
  *   cand_metric_dev [B][L] float64, cand_ok_dev [B][L] CRC flags
