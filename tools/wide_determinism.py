@@ -23,4 +23,22 @@ for L in (64, 128, 256):
         if not (np.array_equal(np.packbits(ci[:nn], axis=1), ref.cand_info[i, :nn].cpu().numpy()) and np.array_equal(cm[:nn], ref.cand_metric[i, :nn].cpu().numpy())):
             bad += 1; print("differs from the oracle", L, int(i))
     print(f"L={L}: 5 runs of {B} frames compared, 4 frames against the oracle; problems so far {bad}", flush=True)
+# ---- frames drawn from the launch's counter (skip_if_hard_ok): which wave decodes a frame varies from run to run, its rows must not
+info = torch.from_numpy(rng.integers(0, 256, (B, 55), dtype=np.uint8)).to(eng.device)
+code = eng.polar_encode(info).cpu().numpy().astype(np.float64)
+clean = (2.0 * code - 1.0) * 6.0
+mix = np.where((rng.random(B) < 0.6)[:, None], q, clean).astype(np.float32)            # 40 % of the frames pass the hard decision
+xm = torch.from_numpy(mix).to(eng.device)
+eng.set_option("scl_multi", 1); eng.set_option("scl_lanes", 1)
+for L in (2, 8, 16, 64):
+    full = eng.scl(xm, list_size=L, skip_if_hard_ok=False); torch.cuda.synchronize()
+    took = ~full.hard_ok.bool()
+    for rep in range(6):
+        r = eng.scl(xm, list_size=L, skip_if_hard_ok=True); torch.cuda.synchronize()
+        for nm in ("cand_info", "cand_metric", "cand_ok", "ncand"):
+            if not torch.equal(getattr(full, nm)[took], getattr(r, nm)[took]) or bool(getattr(r, nm)[~took].to(torch.float64).abs().sum().item()):
+                bad += 1; print("drawn frames: difference", L, rep, nm)
+        if not (torch.equal(full.hard_info, r.hard_info) and torch.equal(full.hard_ok, r.hard_ok)):
+            bad += 1; print("drawn frames: hard decision differs", L, rep)
+    print(f"L={L}: 6 launches with drawn frames ({int(took.sum())} of {B} listed) equal the fixed-group launch; problems so far {bad}", flush=True)
 print("RESULT:", "clean" if bad == 0 else f"{bad} problems")
