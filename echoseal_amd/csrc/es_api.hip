@@ -400,7 +400,7 @@ int es_scl_batch(es_ctx* ctx, const void* llr_dev, int dtype, int64_t B, int lis
     // once the batch yields about one such wave per SIMD -- earlier for long lists, never for L = 1; it needs that kernel's slab
     // (list_size_max > 32, or es_set_option "scl_lane_slab").
     const long long wide_waves = (long long)B * lp / 64;
-    const long long wide_min = (lp == 2 ? 3072LL : lp <= 8 ? 1024LL : lp == 16 ? 768LL : 256LL) * ctx->num_cu / 256;
+    const long long wide_min = (lp <= 8 ? 1024LL : lp == 16 ? 768LL : 256LL) * ctx->num_cu / 256;      // (L = 2: 4.3 against 4.6 ms at 32 768 frames, 6.9 against 8.1 at 65 536)
     const bool lane_auto = ctx->scl_lanes == 0 && ctx->scl_multi < 0 && ctx->d_wide_scratch && lp >= 2 && wide_waves >= wide_min;
     if ((ctx->scl_lanes == 1 && ctx->scl_multi != 0) || lane_auto)
         return es_launch_scl_wide(ctx, llr_dev, dtype, B, list_size, skip_if_hard_ok, hard_info_dev, hard_ok_dev,
