@@ -1,8 +1,8 @@
 """Randomised parity of the run-time-K list decoder (es_scl_wide_kernel<L, LF, true>) against the oracle built for the same code:
 random K in 9..1024, list sizes 1..256 (powers of two and not), ragged batches, float32 / float64 LLRs of several kinds.
-    python3 tools/fuzz_codes.py [SEEDS]"""
+    python3 tests/fuzz/fuzz_codes.py [SEEDS]"""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle.oracle as orc
 from echoseal_amd.engine import RxEngine
 orc.build()

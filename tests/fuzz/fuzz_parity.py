@@ -2,7 +2,7 @@
 quantised LLRs for the list decoders (one-frame kernel vs 16-paths-per-wave kernel vs oracle), scaled / sparse /
 repeated records for the float32 sync screen vs the float64 path, noise records for the screened shift search vs oracle."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle.oracle as orc
 from echoseal_amd.engine import RxEngine
 from echoseal_amd.tables import pack_tables

@@ -1,6 +1,6 @@
 """Randomised parity of the wide list decoder (L = 64, 128, 256) against the oracle on tie-heavy (quantised) LLRs."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle.oracle as orc
 from echoseal_amd.engine import RxEngine
 orc.build()

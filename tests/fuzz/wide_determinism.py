@@ -1,7 +1,7 @@
 """Repeat-run determinism of the lane-per-path list decoder at L = 64 / 128 / 256 (several waves per frame: any missing barrier would
 show up as run-to-run differences), plus a spot check of a few frames against the oracle."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle.oracle as orc
 from echoseal_amd.engine import RxEngine
 orc.build()
