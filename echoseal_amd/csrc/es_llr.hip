@@ -2,7 +2,7 @@
 // for gfx950: matched filter -> integer chip-shift search -> PN despread -> robust scaling.
 //
 // One WAVE per frame record, one-wave blocks (round 1 used a 256-thread block per record: ~14 block barriers and phases in
-// which three of four waves waited for the fourth -- 2.3 ms per 65 536 records against 1.4 ms now).  LDS per wave 16.5 KB.
+// which three of four waves waited for the fourth -- 2.3 ms per 65 536 records against 1.4 ms now).  LDS per wave 17.2 KB.
 //
 // Numerics follow the reference's NumPy float32 data flow step by step:
 //   * matched filter: float64 accumulation of exact float32 products, ascending sample order,
@@ -15,7 +15,7 @@
 //     xor-shuffles 1,2 (inside a leaf) and 4,8,16,32 (across leaves).  Absent leaves contribute
 //     +0.0, which is exact;
 //   * medians are exact order statistics (block-wide 8-bit-digit radix select on the 32-bit keys);
-//   * the matched filter is register tiled: 6 consecutive outputs per thread slide over the
+//   * the matched filter is register tiled: 7 consecutive outputs per thread slide over the
 //     samples they share (zero-padded in LDS, so the tap loop has no bounds).
 //
 // Build with -ffp-contract=off.
@@ -27,7 +27,10 @@ constexpr int NPAY = ES_POLAR_N;
 constexpr int PAYLOAD_START = ES_PRE_L + ES_HDR_L;   // 191
 constexpr int MAX_RX = NPAY + ES_MAX_TAPS;           // prefix + payload
 constexpr int MAX_WIN = NPAY + 2 * ES_MAX_TAPS + 8;  // matched-filter window
-constexpr int MF_R = 6;                              // matched-filter outputs per thread
+#ifndef ES_LLR_MF_R
+#define ES_LLR_MF_R 7
+#endif
+constexpr int MF_R = ES_LLR_MF_R;                              // matched-filter outputs per thread (odd: a lane stride of 7 words is free of LDS bank conflicts; 6 was two-way)
 constexpr int MF_PAD = 176;                          // >= ES_MAX_TAPS rounded up to a multiple of MF_R, + slack
 
 struct PwPlan { int start[16]; int len[16]; };
@@ -232,15 +235,15 @@ __device__ float wave_median_hist_f32(uint32_t (*hist)[256], int n, int lane, F 
 }
 
 // ---- the demodulator: one WAVE per record ----------------------------------------------------------------------------
-// A record belongs to one wave from the first load to the last store: no block barriers.  LDS per wave is 16.5 KB -- the PN
+// A record belongs to one wave from the first load to the last store: no block barriers.  LDS per wave is 17.2 KB -- the PN
 // symbols stay packed, |win| is taken on the fly, only the float64 prefix sums that the 2 x (2 max_shift + 1) window ends need
 // are kept, and regions are reused across phases -- and a block is one wave, so that it fits beside three resident
 // list-decoder blocks (41 KB of LDS left) and nine fit an otherwise empty CU.
-constexpr int LW_WAVES = 1;                           // one-wave blocks (16.5 KB of LDS): they fit beside three resident list-decoder blocks
+constexpr int LW_WAVES = 1;                           // one-wave blocks (17.2 KB of LDS): they fit beside three resident list-decoder blocks
 constexpr int LW_NSH = 2 * ES_MAX_TAPS + 8;          // shifts, at most
 struct LlrWaveLds {
     union {
-        struct { float rx[MF_PAD + MAX_RX + MF_PAD]; float h[MF_PAD]; } mf;     // matched-filter inputs, zero padded
+        struct { float rx[MF_PAD + MAX_RX + MF_PAD]; double h[MF_PAD]; } mf;    // matched-filter inputs, zero padded (taps already as float64: one conversion per tap, not per use)
         double pre[2][LW_NSH];                                               // prefix sums at the window ends of every shift
         float d[NPAY];                                                        // despread values
     } a;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
             const int ii = i - MF_PAD;
             W.a.mf.rx[i] = (ii >= 0 && ii < nfull) ? (float)fr[PAYLOAD_START - prefix + ii] : 0.0f;
         }
-        for (int i = lane; i < MF_PAD; i += 64) W.a.mf.h[i] = (i < ntaps) ? tabs->taps[bi][i] : 0.0f;
+        for (int i = lane; i < MF_PAD; i += 64) W.a.mf.h[i] = (i < ntaps) ? (double)tabs->taps[bi][i] : 0.0;
         const int n = NPAY < npl ? NPAY : npl;                        // :337
         if (lane < 32) {                                              // 32 PN bits per lane, MSB first, from the packed row (:306-312)
             const uint8_t* pnr = pn_rows + rec * ES_PN_BYTES;
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
                     for (int u = 0; u < MF_R; ++u) x[MF_R - 1 + u] = (double)px[MF_R - 1 + u];
                     #pragma unroll
                     for (int u = 0; u < MF_R; ++u) {
-                        const double hk = (double)W.a.mf.h[kb - u];
+                        const double hk = W.a.mf.h[kb - u];
                         #pragma unroll
                         for (int r = 0; r < MF_R; ++r) acc[r] = __builtin_fma(x[u + r], hk, acc[r]);
                     }

@@ -26,6 +26,9 @@ def front():
     thr, peaks, npeaks, flags = eng.sync_fused(y, y32, band)
     return eng.llr(y, band, pn, start=peaks[:, 0].clamp(min=0).contiguous(), variant=0)
 t_front, llr = best(front)
+y_, y32_ = eng.bpf2(win, band); thr_, peaks_, np_, fl_ = eng.sync_fused(y_, y32_, band); st_ = peaks_[:, 0].clamp(min=0).contiguous()
+t_bpf, _ = best(lambda: eng.bpf2(win, band)); t_sync, _ = best(lambda: eng.sync_fused(y_, y32_, band)); t_llr, _ = best(lambda: eng.llr(y_, band, pn, start=st_, variant=0))
+print(f"   band-pass {t_bpf:.3f} ms, fused sync {t_sync:.3f} ms, demodulator {t_llr:.3f} ms")
 t_scl, scl = best(lambda: eng.scl(llr, list_size=8, skip_if_hard_ok=True))
 g = torch.Generator(device=dev); g.manual_seed(1)
 rnd = torch.clamp(3.0 * torch.randn(llr.shape, device=dev, generator=g), -12, 12)
