@@ -20,6 +20,7 @@
 //
 // Build with -ffp-contract=off.
 #include "es_internal.h"
+#include <cstdio>
 
 namespace {
 
@@ -255,6 +256,17 @@ struct LlrWaveLds {
     uint32_t pnw[32];                                                         // payload PN bits, first = MSB of word 0
 };
 
+#ifdef ES_LLR_STAMPS
+// Diagnostic build: cycles per phase, summed over the records of a launch.  The stamps are atomics, i.e. vector-memory operations: the first
+// interval that waits on vmcnt (the sample loads) also waits for them, so "load" reads several times too large (the load phase alone, with
+// the arithmetic compiled out, is 0.13 ms of the kernel's 1.2 ms per 65 536 records); the other phases compare with each other.
+__device__ unsigned long long g_llr_dbg[16];
+#define LLR_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0) atomicAdd(&g_llr_dbg[k], _t - t_last); t_last = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LLR_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const double* __restrict__ y, long long B,
         int T, const int32_t* __restrict__ start, const uint8_t* __restrict__ band,
         const uint8_t* __restrict__ pn_rows, int variant, const es_band_tables* __restrict__ tabs,
@@ -266,27 +278,59 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
     auto fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     __builtin_amdgcn_s_setprio(2);      // front-end kernel: issue ahead of a resident list-decoder wave
     const long long stride = (long long)gridDim.x * LW_WAVES;
-    for (long long rec = (long long)blockIdx.x * LW_WAVES + wv; rec < B; rec += stride) {
+    // Per-record metadata one record ahead (start: a scalar load; band), the four tap counts once: a record's first sample request then
+    // waits for nothing -- read at the top of its own turn they were two to three dependent round trips in front of the samples'.
+    const int nt0 = tabs->ntaps[0], nt1 = tabs->ntaps[1], nt2 = tabs->ntaps[2], nt3 = tabs->ntaps[3];
+    static_assert(LW_WAVES == 1, "the record index below is the block index: wave-uniform by construction, so that the metadata loads are scalar");
+    long long rec = (long long)blockIdx.x;
+    int st_next = (rec < B && start) ? start[rec] : 0;
+    int bi_next = (rec < B) ? band[rec] : 0;
+    for (; rec < B; rec += stride) {
+#ifdef ES_LLR_STAMPS
+        unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
         float* out = llr + rec * NPAY;
-        const int st0 = start ? start[rec] : 0;
+        const int st0 = st_next;
+        const int bi = bi_next;
         int flen = T - st0; if (flen > ES_FRAME_LEN) flen = ES_FRAME_LEN;
-        const int bi = band[rec];
-        const int ntaps = tabs->ntaps[bi];
+        const int ntaps = bi == 0 ? nt0 : bi == 1 ? nt1 : bi == 2 ? nt2 : nt3;
         const int mem = ntaps - 1;
         const int npl = flen - PAYLOAD_START;                         // payload samples present
         if (st0 < 0 || npl <= 0) {                                    // detector.py:320-325
             for (int i = lane; i < NPAY; i += 64) out[i] = 0.0f;
             if (lane == 0) { if (best_s_out) best_s_out[rec] = 0; if (score_out) { score_out[2 * rec] = -1.0f; score_out[2 * rec + 1] = -1.0f; } }
+            const long long nrec = rec + stride;                      // (the next record's metadata: see below)
+            st_next = (nrec < B && start) ? start[nrec] : 0;
+            bi_next = (nrec < B) ? band[nrec] : 0;
             continue;
         }
         const double* fr = y + rec * T + st0;
         const int prefix = mem < PAYLOAD_START ? mem : PAYLOAD_START; // :327
         const int nfull = prefix + npl;
-        for (int i = lane; i < MF_PAD + MAX_RX + MF_PAD; i += 64) {
-            const int ii = i - MF_PAD;
-            W.a.mf.rx[i] = (ii >= 0 && ii < nfull) ? (float)fr[PAYLOAD_START - prefix + ii] : 0.0f;
+        LLR_STAMP(8);
+        {
+            // All the record's samples are requested before the first one is used: unconditional loads from clamped addresses, no
+            // control flow between a load and its use (a bounds test per element made the compiler wait for every load where it was
+            // issued: 19 dependent round trips to HBM per record; 1.39 -> 1.21 ms per 65 536 records).  The pads are plain LDS stores.
+            constexpr int NLD = (MAX_RX + 63) / 64;
+            const double* src = fr + (PAYLOAD_START - prefix);
+            double v[NLD];
+            float tp[(MF_PAD + 63) / 64];
+            #pragma unroll
+            for (int k = 0; k < NLD; ++k) { const int ii = lane + 64 * k; v[k] = src[ii < nfull ? ii : nfull - 1]; }
+            #pragma unroll
+            for (int k = 0; k < (MF_PAD + 63) / 64; ++k) { const int i = lane + 64 * k; tp[k] = tabs->taps[bi][i < ntaps ? i : ntaps - 1]; }
+            {   // the next record's metadata: scalar loads that complete under the wait for this record's samples
+                const long long nrec = rec + stride;
+                st_next = (nrec < B && start) ? start[nrec] : 0;
+                bi_next = (nrec < B) ? band[nrec] : 0;
+            }
+            for (int i = lane; i < MF_PAD; i += 64) { W.a.mf.rx[i] = 0.0f; W.a.mf.rx[MF_PAD + MAX_RX + i] = 0.0f; }
+            #pragma unroll
+            for (int k = 0; k < NLD; ++k) { const int ii = lane + 64 * k; if (ii < MAX_RX) W.a.mf.rx[MF_PAD + ii] = (ii < nfull) ? (float)v[k] : 0.0f; }
+            #pragma unroll
+            for (int k = 0; k < (MF_PAD + 63) / 64; ++k) { const int i = lane + 64 * k; if (i < MF_PAD) W.a.mf.h[i] = (i < ntaps) ? (double)tp[k] : 0.0; }
         }
-        for (int i = lane; i < MF_PAD; i += 64) W.a.mf.h[i] = (i < ntaps) ? (double)tabs->taps[bi][i] : 0.0;
         const int n = NPAY < npl ? NPAY : npl;                        // :337
         if (lane < 32) {                                              // 32 PN bits per lane, MSB first, from the packed row (:306-312)
             const uint8_t* pnr = pn_rows + rec * ES_PN_BYTES;
@@ -298,6 +342,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
             W.pnw[lane] = (uint32_t)(v >> (8 - sh));
         }
         fence();
+        LLR_STAMP(0);
         auto pn_sym = [&](int i) { return ((W.pnw[i >> 5] >> (31 - (i & 31))) & 1u) ? 1.0f : -1.0f; };
 
         // ---- geometry (:335-363)
@@ -347,6 +392,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
             }
         }
         fence();
+        LLR_STAMP(1);
 
         // ---- shift search (:366-379): score(s) = mean(|win[base+s+i] * pn[i]|, i >= guard).  pn[i] is +-1, so |win * pn| ==
         // |win| exactly: the scores are NumPy pairwise sums over sliding windows of |win|.  (The sums themselves cannot slide:
@@ -383,6 +429,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
             for (int j = j0; j < j1; ++j) { run += (double)__builtin_fabsf(W.win[j]); put(j + 1, run); }
         }
         fence();
+        LLR_STAMP(2);
         const bool finite_all = total < 1.0e37;                      // float32 sums cannot overflow below this
         double a1 = -1.0, a2 = -1.0;                                 // two largest exact-sum scores (with multiplicity)
         for (int u = lane; u < nshift; u += 64) {
@@ -411,6 +458,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
             ncand += __popcll(mb);
         }
         fence();
+        LLR_STAMP(3);
         float best = -1.0f, second = -1.0f; int best_s = 0;
         for (int ci = 0; ci < ncand; ++ci) {                         // ascending shift: the first maximum wins (strict > in the reference)
             const int s = W.b.sh.cand[ci];
@@ -420,6 +468,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
             else if (score > second) second = score;
         }
 
+        LLR_STAMP(4);
         // ---- despread at the chosen shift (:382-385)
         const int a0 = base + best_s;
         fence();
@@ -432,9 +481,11 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
         const float* tail = W.a.d + toff;
         const float medv = wave_median_hist_f32(W.b.hist, nt, lane, [&](int i) { return tail[i]; });
         const float madv = wave_median_hist_f32(W.b.hist, nt, lane, [&](int i) { return __builtin_fabsf(tail[i] - medv); });
+        LLR_STAMP(5);
         PwPlan tp; pw_plan_build(tp, nt);
         const float mu = wave_pairwise_sum(tp, lane, [&](int i) { return tail[i]; }) / (float)nt;
         const float var = wave_pairwise_sum(tp, lane, [&](int i) { const float c = tail[i] - mu; return c * c; }) / (float)nt;
+        LLR_STAMP(6);
         const double mad = (double)madv + 1e-12;
         const double sigma_mad = 1.4826 * mad;
         const double sigma_std = (double)__builtin_sqrtf(var) + 1e-12;
@@ -458,6 +509,7 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
             if (score_out) { score_out[2 * rec] = best; score_out[2 * rec + 1] = second; }
         }
         fence();
+        LLR_STAMP(7);
     }
 }
 
@@ -592,6 +644,17 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(es_llr_wave_kernel, dim3((unsigned)blocks), dim3(64 * LW_WAVES), 0, st, y, (long long)B, T,
                        start, band, pn, variant, ctx->d_tables, llr, best_s, score);
+#ifdef ES_LLR_STAMPS
+    {   // diagnostic build only: share of the phases, summed over the records of this launch
+        unsigned long long h[16]; static const unsigned long long z[16] = {0};
+        (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_llr_dbg), sizeof h); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_llr_dbg), z, sizeof z);
+        const char* nm[9] = {"load", "matched filter", "prefix sums", "scores+candidates", "exact candidate sums", "despread+medians", "mean/var", "scale+store", "meta"};
+        unsigned long long tot = 0; for (int k = 0; k < 9; ++k) tot += h[k];
+        fprintf(stderr, "[llr stamps B=%lld]", (long long)B);
+        for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * h[k] / (tot ? tot : 1));
+        fprintf(stderr, "\n");
+    }
+#endif
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }
