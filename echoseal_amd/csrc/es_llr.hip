@@ -165,10 +165,12 @@ __device__ __forceinline__ float key_f32(uint32_t k)
     float x; __builtin_memcpy(&x, &b, 4); return x;
 }
 
-// k-th smallest 32-bit key of key(i), i in [0, n), by ONE wave: four 8-bit-digit passes on four private LDS histograms
-// (lane & 3: the leading byte of a float takes few values, and 64 lanes adding to one word would serialise), wave scan.
-template <typename F>
-__device__ uint32_t wave_select_key32(uint32_t (*hist)[256], int n, int k, int lane, F key)
+// k-th smallest of the wave's keys by ONE wave: four 8-bit-digit passes on four private LDS histograms (lane & 3: the leading byte of a
+// float takes few values, and 64 lanes adding to one word would serialise), wave scan.  The keys (at most SEL_KPL per lane, kx[u] = key of
+// element lane + 64 u, `nmine` of them valid) live in registers for all four passes: read from LDS inside each pass they cost a
+// dependent round trip per element and pass.
+constexpr int SEL_KPL = NPAY / 64;
+__device__ uint32_t wave_select_key32(uint32_t (*hist)[256], const uint32_t (&kx)[SEL_KPL], int nmine, int k, int lane)
 {
     uint32_t prefix = 0;
     int kk = k;
@@ -178,10 +180,9 @@ __device__ uint32_t wave_select_key32(uint32_t (*hist)[256], int n, int k, int l
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         const uint32_t himask = (shift == 24) ? 0u : (~0u << (shift + 8));
         uint32_t* const myh = hist[lane & 3];
-        for (int i = lane; i < n; i += 64) {
-            const uint32_t kx = key(i);
-            if ((kx & himask) == prefix) atomicAdd(&myh[(kx >> shift) & 255u], 1u);
-        }
+        #pragma unroll
+        for (int u = 0; u < SEL_KPL; ++u)
+            if (u < nmine && (kx[u] & himask) == prefix) atomicAdd(&myh[(kx[u] >> shift) & 255u], 1u);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         uint32_t h[4];
         #pragma unroll
@@ -210,20 +211,25 @@ __device__ uint32_t wave_select_key32(uint32_t (*hist)[256], int n, int k, int l
     return prefix;
 }
 
-// NumPy median of val(i), i in [0, n), by one wave: one select; for even n the upper middle element comes from one
+// NumPy median of val(i), i in [0, n), n <= NPAY, by one wave: one select; for even n the upper middle element comes from one
 // counting pass (it is the lower one again if enough keys are <= it, else the smallest key above it).
 template <typename F>
 __device__ float wave_median_hist_f32(uint32_t (*hist)[256], int n, int lane, F val)
 {
-    auto key = [&](int i) { return f32_key(val(i)); };
-    if (n & 1) return key_f32(wave_select_key32(hist, n, n / 2, lane, key));
+    uint32_t kx[SEL_KPL];
+    const int nmine = (n > lane) ? (n - lane + 63) / 64 : 0;            // elements lane, lane + 64, ... below n
+    #pragma unroll
+    for (int u = 0; u < SEL_KPL; ++u) kx[u] = (u < nmine) ? f32_key(val(lane + 64 * u)) : 0xffffffffu;
+    if (n & 1) return key_f32(wave_select_key32(hist, kx, nmine, n / 2, lane));
     const int k_lo = n / 2 - 1, k_hi = n / 2;
-    const uint32_t key_lo = wave_select_key32(hist, n, k_lo, lane, key);
+    const uint32_t key_lo = wave_select_key32(hist, kx, nmine, k_lo, lane);
     int le = 0; uint32_t nxt = 0xffffffffu;
-    for (int i = lane; i < n; i += 64) {
-        const uint32_t kx = key(i);
-        le += kx <= key_lo;
-        if (kx > key_lo && kx < nxt) nxt = kx;
+    #pragma unroll
+    for (int u = 0; u < SEL_KPL; ++u) {
+        if (u < nmine) {
+            le += kx[u] <= key_lo;
+            if (kx[u] > key_lo && kx[u] < nxt) nxt = kx[u];
+        }
     }
     #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
