@@ -589,12 +589,20 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
     int bad = 0;
     {
         uint32_t* const myh = S.hist[lane & (PW_HCOPIES - 1)];
-        for (int i = lane; i < n; i += 64) {
-            const float v = c[i];
-            bad |= !(__builtin_fabsf(v) < 1e30f);                       // inf / nan / absurd: screen unusable
-            int b = (int)((v + 1.0f) * 128.0f);
-            b = b < 0 ? 0 : (b > 255 ? 255 : b);
-            atomicAdd(&myh[b], 1u);
+        for (int i0 = lane; i0 < n; i0 += 64 * 8) {                     // eight row values read before the first histogram update (LDS reads
+            float v8[8];                                                //  and LDS atomics: in a plain loop each read waited behind the last update)
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; v8[u] = c[i < n ? i : n - 1]; }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + 64 * u < n) {
+                    const float v = v8[u];
+                    bad |= !(__builtin_fabsf(v) < 1e30f);               // inf / nan / absurd: screen unusable
+                    int b = (int)((v + 1.0f) * 128.0f);
+                    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+                    atomicAdd(&myh[b], 1u);
+                }
+            }
         }
     }
     wave_fence_lds();
