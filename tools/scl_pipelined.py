@@ -1,9 +1,12 @@
 """SCL-8 alone, pipelined: N engines on N streams, each launching 65 536-frame batches back to back (no front end) -- the steady-state rate of
-the list decoder when the tails of one launch are filled by the next.  python3 tools/scl_pipelined.py [LANES]"""
+the list decoder when the tails of one launch are filled by the next.  python3 tools/scl_pipelined.py [LANES] [BUILD]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import echoseal_amd._native as nat
+if len(sys.argv) > 2 and sys.argv[2]:
+    nat.LIB_PATH = os.path.join(os.path.dirname(nat.LIB_PATH), f"libechoseal_hip_{sys.argv[2]}.so")
 from echoseal_amd.engine import RxEngine
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dev = torch.device("cuda", 0)
