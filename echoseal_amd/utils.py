@@ -8,6 +8,7 @@ kernels consume.  The AES / HMAC code is our own (echoseal_amd.primitives) becau
 """
 from __future__ import annotations
 
+import functools
 import hashlib
 import hmac
 import math
@@ -26,10 +27,16 @@ BAND_PLAN: list[Tuple[int, int]] = [
 ]
 
 
-def band_index(key: bytes, frame_ctr: int) -> int:
-    """Index into BAND_PLAN for a frame counter: HMAC-SHA256(key, ctr_be32)[0] mod 4."""
-    tag = hmac.new(key, int(frame_ctr).to_bytes(4, "big"), hashlib.sha256).digest()
+@functools.lru_cache(maxsize=1 << 18)
+def _band_index_cached(key: bytes, frame_ctr: int) -> int:
+    tag = hmac.new(key, frame_ctr.to_bytes(4, "big"), hashlib.sha256).digest()
     return tag[0] % len(BAND_PLAN)
+
+
+def band_index(key: bytes, frame_ctr: int) -> int:
+    """Index into BAND_PLAN for a frame counter: HMAC-SHA256(key, ctr_be32)[0] mod 4.  (Memoised: the counter search of one verify() asks
+    for several hundred counters, the same ones clip after clip -- 2 ms of HMACs per call on the host otherwise.)"""
+    return _band_index_cached(bytes(key), int(frame_ctr))
 
 
 def choose_band(key: bytes, frame_ctr: int) -> tuple[int, int]:
