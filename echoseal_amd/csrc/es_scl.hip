@@ -33,6 +33,9 @@
 
 namespace {
 
+#ifndef ES_SCL_FCHAINS
+#define ES_SCL_FCHAINS 4                            /* independent f evaluations in flight in the slot-storage levels (2: 1.5 % slower at 1 024 frames) */
+#endif
 constexpr int GDEPTH = 3;                 // depths 1..GDEPTH live in global scratch
 constexpr int GSLOT = 512 + 256 + 128;    // doubles per path slot in global scratch
 constexpr int LDS_ROW = 136;              // 128 doubles + 8 pad (bank spread between slots)
@@ -219,6 +222,16 @@ __global__ __launch_bounds__(64 * SclCfg<L>::WPB, SclCfg<L>::MIN_WAVES) void es_
                         }
                     } else {
                         int j = j0;
+                        if constexpr (ES_SCL_FCHAINS == 4 && L >= 8)   // (L = 1: four chains are 3.6 % slower; L = 4: no difference; L = 8: 1.3 % faster)
+                        for (; j + 3 * jst < S; j += 4 * jst) {    // four independent f chains in flight (one memory round trip per four elements)
+                            double a0, c0, a1, c1, a2, c2, a3, c3;
+                            load_pair(j, a0, c0); load_pair(j + jst, a1, c1); load_pair(j + 2 * jst, a2, c2); load_pair(j + 3 * jst, a3, c3);
+                            const double o0 = es_polar_f(a0, c0, tab);
+                            const double o1 = es_polar_f(a1, c1, tab);
+                            const double o2 = es_polar_f(a2, c2, tab);
+                            const double o3 = es_polar_f(a3, c3, tab);
+                            store_out(j, o0); store_out(j + jst, o1); store_out(j + 2 * jst, o2); store_out(j + 3 * jst, o3);
+                        }
                         for (; j + jst < S; j += 2 * jst) {        // two independent f chains in flight
                             double a0, c0, a1, c1; load_pair(j, a0, c0); load_pair(j + jst, a1, c1);
                             const double o0 = es_polar_f(a0, c0, tab);
