@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libechoseal_hip.so")
 ES_FRAME_LEN = 1215
 ES_PRE_L = 63
 ES_NBANDS = 4
-ES_MAX_TAPS = 160
+ES_MAX_TAPS = 576
+ES_MAX_TAPS_FAST = 160
 ES_MAX_PEAKS = 32
 ES_MAX_LIST = 256
 ES_PN_BYTES = 152

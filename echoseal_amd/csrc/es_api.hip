@@ -151,6 +151,7 @@ int es_set_tables(es_ctx* ctx, const double* ba, const double* tpl, const float*
         for (int k = 0; k < ES_PRE_L; ++k) { h.tpl[b][k] = tpl[b * ES_PRE_L + k]; h.tpl32[b][k] = (float)tpl[b * ES_PRE_L + k]; }
         if (ntaps[b] < 1 || ntaps[b] > ES_MAX_TAPS) return fail(ctx, ES_EINVAL, "es_set_tables: ntaps out of range");
         h.ntaps[b] = ntaps[b];
+        if (b == 0 || ntaps[b] > ctx->max_ntaps) ctx->max_ntaps = ntaps[b];
         for (int k = 0; k < ntaps[b]; ++k) h.taps[b][k] = taps[b * ES_MAX_TAPS + k];
     }
     uint16_t dpos[ES_POLAR_N];

@@ -29,6 +29,7 @@ struct es_ctx {
 
     es_frozen_mask frozen{};
     int n_info = 0;
+    int max_ntaps = 0;                /* longest matched filter of the tables (picks the demodulator's instantiation) */
 
     /* device-resident tables */
     es_band_tables* d_tables = nullptr;

@@ -26,13 +26,21 @@ namespace {
 
 constexpr int NPAY = ES_POLAR_N;
 constexpr int PAYLOAD_START = ES_PRE_L + ES_HDR_L;   // 191
-constexpr int MAX_RX = NPAY + ES_MAX_TAPS;           // prefix + payload
-constexpr int MAX_WIN = NPAY + 2 * ES_MAX_TAPS + 8;  // matched-filter window
+// Sizes that follow from the longest matched filter the kernel must hold.  Two instantiations: ES_MAX_TAPS_FAST (160: the taps of the
+// default fs_target = 48 000 are 93..131 long) and ES_MAX_TAPS (576: any fs_target the reference's band plan admits down to 44 100 Hz, where
+// the 18-22 kHz band sits at Nyquist and the cascade's impulse response needs 550 taps; rtwm/detector.py:260-294).
 #ifndef ES_LLR_MF_R
 #define ES_LLR_MF_R 7
 #endif
 constexpr int MF_R = ES_LLR_MF_R;                              // matched-filter outputs per thread (odd: a lane stride of 7 words is free of LDS bank conflicts; 6 was two-way)
-constexpr int MF_PAD = 176;                          // >= ES_MAX_TAPS rounded up to a multiple of MF_R, + slack
+template <int MAXT> struct LlrSizes {
+    static constexpr int MAX_RX = NPAY + MAXT;                             // prefix + payload
+    static constexpr int MAX_WIN = NPAY + 2 * MAXT + 8;                    // matched-filter window
+    static constexpr int MF_PAD = (MAXT + MF_R - 1) / MF_R * MF_R + 15;    // >= MAXT rounded up to a multiple of MF_R, + slack (176 at MAXT = 160)
+    static constexpr int LW_NSH = 2 * MAXT + 8;                            // shifts, at most
+    static constexpr int HD_MAXWIN = ES_HDR_L + 2 * MAXT + 8;
+};
+static_assert(LlrSizes<ES_MAX_TAPS_FAST>::MF_PAD == 176, "the default instantiation keeps its layout");
 
 struct PwPlan { int start[16]; int len[16]; };
 
@@ -247,8 +255,9 @@ __device__ float wave_median_hist_f32(uint32_t (*hist)[256], int n, int lane, F 
 // are kept, and regions are reused across phases -- and a block is one wave, so that it fits beside three resident
 // list-decoder blocks (41 KB of LDS left) and nine fit an otherwise empty CU.
 constexpr int LW_WAVES = 1;                           // one-wave blocks (17.2 KB of LDS): they fit beside three resident list-decoder blocks
-constexpr int LW_NSH = 2 * ES_MAX_TAPS + 8;          // shifts, at most
+template <int MAXT>
 struct LlrWaveLds {
+    static constexpr int MAX_RX = LlrSizes<MAXT>::MAX_RX, MAX_WIN = LlrSizes<MAXT>::MAX_WIN, MF_PAD = LlrSizes<MAXT>::MF_PAD, LW_NSH = LlrSizes<MAXT>::LW_NSH;
     union {
         struct { float rx[MF_PAD + MAX_RX + MF_PAD]; double h[MF_PAD]; } mf;    // matched-filter inputs, zero padded (taps already as float64: one conversion per tap, not per use)
         double pre[2][LW_NSH];                                               // prefix sums at the window ends of every shift
@@ -273,14 +282,16 @@ __device__ unsigned long long g_llr_dbg[16];
 #define LLR_STAMP(k) do { } while (0)
 #endif
 
+template <int MAXT>
 __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const double* __restrict__ y, long long B,
         int T, const int32_t* __restrict__ start, const uint8_t* __restrict__ band,
         const uint8_t* __restrict__ pn_rows, int variant, const es_band_tables* __restrict__ tabs,
         float* __restrict__ llr, int32_t* __restrict__ best_s_out, float* __restrict__ score_out)
 {
-    __shared__ __attribute__((aligned(16))) LlrWaveLds s_w[LW_WAVES];
+    constexpr int MAX_RX = LlrSizes<MAXT>::MAX_RX, MF_PAD = LlrSizes<MAXT>::MF_PAD;
+    __shared__ __attribute__((aligned(16))) LlrWaveLds<MAXT> s_w[LW_WAVES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    LlrWaveLds& W = s_w[wv];
+    LlrWaveLds<MAXT>& W = s_w[wv];
     auto fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     __builtin_amdgcn_s_setprio(2);      // front-end kernel: issue ahead of a resident list-decoder wave
     const long long stride = (long long)gridDim.x * LW_WAVES;
@@ -524,7 +535,6 @@ __global__ __launch_bounds__(64 * LW_WAVES, 3) void es_llr_wave_kernel(const dou
 // |sum(win * hdr_pn)[guard:]| (first maximum in ascending shift order), then 16 x 8 majority.
 // Eight shifts are scored at a time: lane = slot*8 + accumulator reproduces NumPy's <=128-element
 // pairwise leaf (8 strided accumulators, ((0+1)+(2+3))+((4+5)+(6+7)), tail added sequentially).
-constexpr int HD_MAXWIN = ES_HDR_L + 2 * ES_MAX_TAPS + 8;
 
 // NumPy pairwise leaf (8 <= n <= 128) evaluated by the 8 lanes of a slot; all 8 lanes return it.
 template <typename F>
@@ -540,13 +550,15 @@ __device__ __forceinline__ float slot_leaf_sum(int n, int j, F get)
     return r;
 }
 
+template <int MAXT>
 __global__ __launch_bounds__(64) void es_header_kernel(const double* __restrict__ y, long long B, int T,
         const int32_t* __restrict__ start, const uint8_t* __restrict__ band, const uint8_t* __restrict__ hdr_pn,
         const es_band_tables* __restrict__ tabs, uint8_t* __restrict__ ok_out, int32_t* __restrict__ val_out,
         float* __restrict__ score_out, int32_t* __restrict__ best_s_out)
 {
     __shared__ float s_rx[ES_PRE_L + ES_HDR_L];
-    __shared__ float s_h[ES_MAX_TAPS];
+    constexpr int HD_MAXWIN = LlrSizes<MAXT>::HD_MAXWIN;
+    __shared__ float s_h[MAXT];
     __shared__ float s_pn[ES_HDR_L];
     __shared__ float s_win[HD_MAXWIN];
     __shared__ float s_d[ES_HDR_L];
@@ -648,8 +660,12 @@ int es_launch_llr(es_ctx* ctx, const double* y, int64_t B, int T, const int32_t*
     long long blocks = (B + LW_WAVES - 1) / LW_WAVES;
     const long long cap = (long long)ctx->num_cu * 64 / LW_WAVES;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(es_llr_wave_kernel, dim3((unsigned)blocks), dim3(64 * LW_WAVES), 0, st, y, (long long)B, T,
-                       start, band, pn, variant, ctx->d_tables, llr, best_s, score);
+    if (ctx->max_ntaps <= ES_MAX_TAPS_FAST)
+        hipLaunchKernelGGL(es_llr_wave_kernel<ES_MAX_TAPS_FAST>, dim3((unsigned)blocks), dim3(64 * LW_WAVES), 0, st, y, (long long)B, T,
+                           start, band, pn, variant, ctx->d_tables, llr, best_s, score);
+    else                                                                      // long matched filters (fs_target other than 48 000): 41 KB of LDS per wave
+        hipLaunchKernelGGL(es_llr_wave_kernel<ES_MAX_TAPS>, dim3((unsigned)blocks), dim3(64 * LW_WAVES), 0, st, y, (long long)B, T,
+                           start, band, pn, variant, ctx->d_tables, llr, best_s, score);
 #ifdef ES_LLR_STAMPS
     {   // diagnostic build only: share of the phases, summed over the records of this launch
         unsigned long long h[16]; static const unsigned long long z[16] = {0};
@@ -671,8 +687,12 @@ int es_launch_header(es_ctx* ctx, const double* y, int64_t B, int T, const int32
     long long blocks = B;
     const long long cap = (long long)ctx->num_cu * 32;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(es_header_kernel, dim3((unsigned)blocks), dim3(64), 0, st, y, (long long)B, T, start, band,
-                       hdr_pn, ctx->d_tables, ok, val, score, best_s);
+    if (ctx->max_ntaps <= ES_MAX_TAPS_FAST)
+        hipLaunchKernelGGL(es_header_kernel<ES_MAX_TAPS_FAST>, dim3((unsigned)blocks), dim3(64), 0, st, y, (long long)B, T, start, band,
+                           hdr_pn, ctx->d_tables, ok, val, score, best_s);
+    else
+        hipLaunchKernelGGL(es_header_kernel<ES_MAX_TAPS>, dim3((unsigned)blocks), dim3(64), 0, st, y, (long long)B, T, start, band,
+                           hdr_pn, ctx->d_tables, ok, val, score, best_s);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_OK;
 }

@@ -59,11 +59,14 @@ class WatermarkDetector:
     # ------------------------------------------------------------------ engine plumbing
     @property
     def engine(self):
-        if self._engine is None:
-            from .fastpolar import default_engine
-            self._engine = default_engine()
-        if self._engine.fs != self.fs_target:
-            raise NotImplementedError("the GPU tables are built for fs_target = %d" % self._engine.fs)
+        if self._engine is None or self._engine.fs != self.fs_target:
+            from .fastpolar import engine_for_fs
+            try:
+                self._engine = engine_for_fs(self.fs_target)       # tables (band-pass, template, taps) of this rate
+            except ValueError as e:                                 # SciPy's own error (band above Nyquist) passes through, as in the reference
+                if "taps" not in str(e):
+                    raise
+                raise NotImplementedError(f"fs_target = {self.fs_target}: {e} (DESIGN.md section 7)") from None
         return self._engine
 
     def _band_id(self, band) -> int:

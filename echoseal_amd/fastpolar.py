@@ -48,6 +48,24 @@ def engine_for(K: int):
     return _other[1]
 
 
+_other_fs = None       # (fs, engine) of the last fs_target other than 48 000 a detector was built for
+
+
+def engine_for_fs(fs: int):
+    """The engine a `WatermarkDetector(fs_target=fs)` runs on: the process-wide one for 48 000, else one engine whose tables (band-pass,
+    preamble template, matched-filter taps) are built for that rate (one at a time, like `engine_for`)."""
+    global _other_fs
+    if fs == 48_000:
+        return default_engine()
+    if _other_fs is None or _other_fs[0] != fs:
+        import torch
+        from .engine import RxEngine
+        if _other_fs is not None:
+            _other_fs[1].close()
+        _other_fs = (fs, RxEngine(torch.cuda.current_device() if torch.cuda.is_available() else 0, list_size_max=256, fs=fs))
+    return _other_fs[1]
+
+
 def _reliability_order(N: int) -> np.ndarray:
     rel = np.asarray(Q_NMAX_1024, dtype=np.int64)
     if rel.size != N:

@@ -18,7 +18,7 @@ from scipy.signal import lfilter
 from .reliability import Q_NMAX_1024
 from .utils import BAND_PLAN, butter_bandpass, mseq_63
 
-MAX_TAPS = 160
+MAX_TAPS = 576          # ES_MAX_TAPS: row stride of the tap table (the kernels' small-footprint instantiation serves up to 160)
 
 
 @lru_cache(maxsize=None)

@@ -37,7 +37,8 @@ extern "C" {
 #define ES_POLAR_K      448
 #define ES_INFO_BYTES    55
 #define ES_NBANDS         4
-#define ES_MAX_TAPS     160   /* reference taps are 93..131 long (rtwm/detector.py:260-294) */
+#define ES_MAX_TAPS     576   /* row stride of the tap table: the reference's taps are 93..131 long at fs_target = 48 000, 550 at 44 100 (rtwm/detector.py:260-294) */
+#define ES_MAX_TAPS_FAST 160  /* up to here the demodulator runs its small-footprint instantiation */
 #define ES_MAX_PEAKS     32   /* detector consumes at most 25 peaks per scan (rtwm/detector.py:108) */
 #define ES_MAX_LIST     256   /* any list size 1..256; the mapping of paths to lanes is chosen per launch (es_set_option) */
 #define ES_PN_BYTES     152   /* ceil(1215 / 8): packed PN row of one frame counter */
@@ -60,7 +61,8 @@ int         es_info_bytes(const es_ctx* ctx);          /* bytes of one packed in
 /* Static per-band tables (host pointers).
  *   ba      [4][18]  Butterworth b[9] then a[9], float64      <- rtwm/utils.py:52-55 butter_bandpass
  *   tpl     [4][63]  unit-norm cascaded preamble template      <- rtwm/detector.py:67-69
- *   taps    [4][ES_MAX_TAPS] float32 matched-filter taps, zero padded <- rtwm/detector.py:260-294
+ *   taps    [4][ES_MAX_TAPS] float32 matched-filter taps, zero padded <- rtwm/detector.py:260-294 (any fs_target whose filters fit:
+ *           93..131 taps at 48 000 Hz, 550 at 44 100; above ES_MAX_TAPS_FAST the demodulator runs its large-footprint instantiation)
  *   ntaps   [4]
  *   frozen  [1024]   1 = frozen bit                            <- rtwm/fastpolar.py:225-226
  * The mask leaves K information positions (information bits + CRC-8): 448 for the reference's own code (rtwm/polar_fast.py:8-9) and for

@@ -3,7 +3,7 @@
 REFERENCE, captured by running it (build container only; /root/reference is read-only and never travels).  Only inputs
 and outputs are stored under tests/golden/ -- no reference source.
 
-    python -m oracle.refshim.gen_golden_r3 [all|inputs|sweep_default|sweep_glibc|codes|codes2]
+    python -m oracle.refshim.gen_golden_r3 [all|inputs|sweep_default|sweep_glibc|codes|codes2|fs]
 
     polar_sweep_{default,glibc}.npz   for each L in (1, 4, 16): 256 LLR vectors through the reference's
         PolarCode.decode(list_size=L) (rtwm/fastpolar.py:254-359): (info, ok), whether the list loop ran, and the final
@@ -222,6 +222,61 @@ def gen_codes(mode, ks=CODES_K, name="polar_codes"):
     np.savez_compressed(os.path.join(GOLD, f"{name}_{mode}.npz"), **out)
 
 
+FS_TARGETS = (44_100, 96_000)
+
+
+def gen_fs(n=24):
+    """WatermarkDetector(fs_target = 44 100 / 96 000) (rtwm/detector.py:27): the band-pass design, the preamble template and the matched
+    filter follow the rate -- 550 taps in the 18-22 kHz band at 44 100 Hz, 229..262 at 96 000 -- and with them the shift range of _llr and
+    _decode_header.  The first `n` C3 windows (the samples are what they are: the detector is told another rate), everything
+    _scan_band_multi_frame computes and _llr (both PN variants) at the first peak, as in gen_golden_r2.gen_c3."""
+    import contextlib, io
+    import numpy as np
+    from oracle.refshim.shim import load_reference
+    load_reference()
+    import rtwm.detector as det_mod
+    from rtwm.detector import WatermarkDetector
+    from rtwm.utils import choose_band, BAND_PLAN, butter_bandpass
+    from scipy.signal import lfilter
+    from echoseal_amd.workloads import c3_windows
+    from oracle.refshim.gen_golden_r2 import scan_capture, ref_frames, best_s_from
+    ctrs = list(range(n))
+    frames, payloads = ref_frames(np, ctrs)
+    win, offs, facs, lens = c3_windows(frames)
+    for fs in FS_TARGETS:
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):
+            rx = WatermarkDetector(KEY, fs_target=fs, list_size=8)
+        out = {"win": win[:n], "ctr": np.array(ctrs, np.int64), "fs": np.array(fs)}
+        bands, thr, fb, npk, peaks, nvis, hdrs, llr0, llr1, bs, ntaps = [], [], [], [], [], [], [], [], [], [], []
+        for i in range(n):
+            band = choose_band(KEY, ctrs[i])
+            cap = scan_capture(np, det_mod, rx, win[i], band)
+            bands.append(BAND_PLAN.index(band))
+            thr.append(cap["thr"]); fb.append(cap["fallback"])
+            pk = np.full(32, -1, np.int32); k = min(32, cap["peaks"].size); pk[:k] = cap["peaks"][:k]
+            peaks.append(pk); npk.append(cap["peaks"].size)
+            h = np.zeros((5, 3)); v = cap["hdr"][:5]; h[:v.shape[0]] = v
+            hdrs.append(h); nvis.append(cap["visited"].size)
+            if i < 4:
+                out[f"corr/{i:03d}"] = cap["corr"]
+            start = int(cap["peaks"][0])
+            b, a = butter_bandpass(*band, fs, order=4)
+            y = lfilter(b, a, win[i].astype(np.float32, copy=False))
+            with contextlib.redirect_stdout(sink):
+                sink.seek(0); sink.truncate()
+                l0 = rx._llr(y[start:start + 1215], ctrs[i], 0)
+                l1 = rx._llr(y[start:start + 1215], ctrs[i], 1)
+                ntaps.append(len(rx._matched_filter_taps(band)))
+            b_s = best_s_from(sink.getvalue())
+            llr0.append(l0); llr1.append(l1); bs.append((b_s + [0, 0])[:2] if len(b_s) >= 2 else [9999, 9999])
+            print(f"  fs {fs} window {i}: band {bands[-1]} taps {ntaps[-1]} thr {cap['thr']:.4f} peaks {cap['peaks'][:3]} best_s {bs[-1]}", flush=True)
+        out.update(band=np.array(bands, np.uint8), thr=np.array(thr), fallback=np.array(fb), npeaks=np.array(npk, np.int32), peaks=np.stack(peaks),
+                   nvisited=np.array(nvis, np.int32), hdr=np.stack(hdrs), llr0=np.stack(llr0), llr1=np.stack(llr1), best_s=np.array(bs, np.int32),
+                   ntaps=np.array(ntaps, np.int32))
+        np.savez_compressed(os.path.join(GOLD, f"fs{fs}_windows.npz"), **out)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
@@ -245,6 +300,8 @@ def main():
         subprocess.check_call([sys.executable, "-m", "oracle.refshim.gen_golden_r3", "codes2_glibc"], cwd=ROOT, env=env)
     elif what in ("codes2_default", "codes2_glibc"):
         gen_codes(what.split("_")[1], CODES2_K, "polar_codes2")
+    elif what == "fs":
+        gen_fs()
     elif what in ("sweep_default", "sweep_glibc"):
         gen_sweep(what.split("_")[1], workers=int(os.environ.get("GOLD_WORKERS", "6")))
     else:

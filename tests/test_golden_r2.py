@@ -119,6 +119,50 @@ def test_c3_windows_header_and_llr_match_reference(oracle, tables):
     assert amb == 0 and exact == rows.size          # observed: every chosen shift equals the reference's; the margin rule excuses nothing here
 
 
+@pytest.mark.parametrize("fs", [44_100, 96_000])
+def test_other_fs_target_matches_reference(oracle, fs):
+    """WatermarkDetector(fs_target = 44 100 / 96 000): band-pass design, preamble template and matched filter follow the rate (550 taps in the
+    18-22 kHz band at 44 100 Hz).  24 C3 windows through the reference built for that rate (oracle/refshim/gen_golden_r3.py fs): tables, sync,
+    header decode at the visited peaks, _llr (both PN variants) at the first peak."""
+    from echoseal_amd.crypto import SecureChannel
+    from echoseal_amd.tables import pack_tables
+    g = _g(f"fs{fs}_windows.npz")
+    tables = pack_tables(fs)
+    ba, tpl, taps, ntaps, _ = tables
+    assert int(ntaps.max()) > 160 and int(ntaps.max()) <= 576
+    sec = SecureChannel(KEY)
+    hdr_pn = sec.pn_bits(0, 128)
+    worst = 0.0
+    for i in range(g["win"].shape[0]):
+        band = int(g["band"][i]); ctr = int(g["ctr"][i])
+        assert int(ntaps[band]) == int(g["ntaps"][i])
+        y, corr, thr, med, mad, peaks, total, fb = _sync(oracle, tables, g["win"][i], band)
+        if f"corr/{i:03d}" in g.files:
+            assert np.max(np.abs(corr - g[f"corr/{i:03d}"])) < 1e-12
+        assert abs(thr - float(g["thr"][i])) < 1e-12 and fb == bool(g["fallback"][i]) and total == int(g["npeaks"][i])
+        k = min(total, 32)
+        assert list(peaks[:k]) == list(g["peaks"][i, :k]), i
+        h = taps[band, :ntaps[band]]
+        visited = [int(p) for p in g["peaks"][i, :min(int(g["npeaks"][i]), 25)] if p + 1215 <= y.size][:5]
+        assert len(visited) == min(5, int(g["nvisited"][i]))
+        for j, st in enumerate(visited):
+            ok, val, score, _ = oracle.decode_header(y[st:st + 1215], hdr_pn, h)
+            assert ok == bool(g["hdr"][i, j, 0]) and val == int(g["hdr"][i, j, 1]), (i, j)
+            assert abs(score - g["hdr"][i, j, 2]) <= 1e-4 * max(1.0, abs(g["hdr"][i, j, 2]))
+        st = int(g["peaks"][i, 0])
+        pn = sec.pn_bits(ctr, 1215)
+        for variant, key, pnb in ((0, "llr0", pn[191:1215]), (1, "llr1", pn[:1024])):
+            llr, best_s, s0, s1 = oracle.llr(y[st:st + 1215], pnb, h)
+            if y.size - st <= 191:
+                assert not llr.any() and not g[key][i].any()
+                continue
+            if best_s != int(g["best_s"][i, variant]):
+                assert (s0 - s1) / max(abs(s0), 1e-30) < 1e-5, (i, variant)     # only a near-tie may differ (SURVEY H1)
+                continue
+            worst = max(worst, float(np.max(np.abs(llr - g[key][i]))))
+    assert worst <= 1e-5, worst
+
+
 def test_multi_peak_records_match_reference(oracle, tables):
     from echoseal_amd.crypto import SecureChannel
     g = _g("sync_multi.npz")

@@ -74,6 +74,66 @@ def test_c3_windows_sync_header_llr_vs_reference(engine):
     assert worst <= 1e-5 and amb == 0, (worst, amb)          # observed: no shift differs (tests/golden/h1_margin_report.json)
 
 
+@pytest.mark.parametrize("fs", [44_100, 96_000])
+def test_other_fs_target_vs_reference(oracle, fs):
+    """An engine whose tables are built for fs_target = 44 100 / 96 000 (matched filters of up to 550 taps: the demodulator's and the header
+    decoder's long-filter instantiations) against the reference built for that rate, and against the oracle bit for bit; then the drop-in
+    detector at that rate runs verify() end to end."""
+    from echoseal_amd.engine import RxEngine
+    from echoseal_amd.tables import pack_tables
+    g = _g(f"fs{fs}_windows.npz")
+    eng = RxEngine(0, list_size_max=8, fs=fs)
+    ba, tpl, taps, ntaps, _ = pack_tables(fs)
+    n = g["win"].shape[0]
+    win, band = _dev(eng, g["win"], g["band"])
+    sec = SecureChannel(KEY)
+    pn, = _dev(eng, sec.pn_bytes_batch([int(c) for c in g["ctr"]], 152))
+    hdr_pn, = _dev(eng, np.packbits(sec.pn_bits(0, 128)).reshape(1, 16))
+    sy = eng.sync_fast(win, band)
+    thr = sy.thr.cpu().numpy(); pk = sy.peaks.cpu().numpy(); npk = sy.npeaks.cpu().numpy()
+    assert np.max(np.abs(thr - g["thr"])) < 1e-12
+    for i in range(n):
+        k = min(int(g["npeaks"][i]), 32)
+        assert (int(npk[i]) & 0xFFFF) == k and bool(npk[i] >> 30) == bool(g["fallback"][i]), i
+        assert list(pk[i, :k]) == list(g["peaks"][i, :k]), i
+    y = sy.y
+    rows, starts, want = [], [], []
+    for i in range(n):
+        vis = [int(p) for p in g["peaks"][i, :min(int(g["npeaks"][i]), 25)] if p + 1215 <= 2048][:5]
+        for j, st in enumerate(vis):
+            rows.append(i); starts.append(st); want.append(g["hdr"][i, j])
+    rows_t = torch.tensor(rows, device=eng.device)
+    ok, val, score = eng.header(y[rows_t].contiguous(), band[rows_t].contiguous(), hdr_pn,
+                                start=torch.tensor(starts, dtype=torch.int32, device=eng.device))
+    want = np.array(want)
+    assert np.array_equal(ok.cpu().numpy().astype(bool), want[:, 0].astype(bool))
+    assert np.array_equal(val.cpu().numpy(), want[:, 1].astype(np.int64))
+    assert np.max(np.abs(score.cpu().numpy() - want[:, 2]) / np.maximum(1.0, np.abs(want[:, 2]))) <= 1e-4
+    start = torch.from_numpy(g["peaks"][:, 0].astype(np.int32)).to(eng.device)
+    yh = y.cpu().numpy()
+    worst = 0.0
+    for variant, key in ((0, "llr0"), (1, "llr1")):
+        llr, best_s, score2 = eng.llr(y, band, pn, start=start, variant=variant, want_diag=True)
+        llr = llr.cpu().numpy(); best_s = best_s.cpu().numpy(); sc = score2.cpu().numpy()
+        for i in range(n):
+            st = int(g["peaks"][i, 0]); b = int(g["band"][i])
+            pnb = sec.pn_bits(int(g["ctr"][i]), 1215)
+            o_llr, o_s, _, _ = oracle.llr(yh[i, st:st + 1215], pnb[191:1215] if variant == 0 else pnb[:1024], taps[b, :ntaps[b]])
+            assert np.array_equal(o_llr, llr[i]) and (2048 - st <= 191 or o_s == int(best_s[i])), (i, variant)      # HIP == oracle, bit for bit
+            if 2048 - st <= 191:
+                assert not llr[i].any() and not g[key][i].any()
+                continue
+            if best_s[i] != g["best_s"][i, variant]:
+                assert (sc[i, 0] - sc[i, 1]) / max(abs(sc[i, 0]), 1e-30) < 1e-5, (i, variant)
+                continue
+            worst = max(worst, float(np.max(np.abs(llr[i] - g[key][i]))))
+    assert worst <= 1e-5, worst
+    eng.close()
+    from rtwm.detector import WatermarkDetector
+    det = WatermarkDetector(KEY, fs_target=fs, list_size=8)
+    assert det.verify(g["win"][:3].reshape(-1).astype(np.float32), fs) in (True, False) and det.engine.fs == fs
+
+
 def test_multi_peak_records_vs_reference(engine):
     g = _g("sync_multi.npz")
     for i in range(int(g["count"])):

@@ -20,7 +20,7 @@ def test_header_and_library_agree():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.es_abi_version() == 1
-    for const, val in (("ES_FRAME_LEN", 1215), ("ES_MAX_TAPS", 160), ("ES_MAX_PEAKS", 32), ("ES_PN_BYTES", 152)):
+    for const, val in (("ES_FRAME_LEN", 1215), ("ES_MAX_TAPS", 576), ("ES_MAX_TAPS_FAST", 160), ("ES_MAX_PEAKS", 32), ("ES_PN_BYTES", 152)):
         assert int(re.search(rf"#define\s+{const}\s+(\d+)", hdr).group(1)) == val == getattr(nat, const)
 
 
@@ -108,7 +108,8 @@ def test_hot_path_fails_loudly_without_gpu():
 def test_declared_limits_raise_not_implemented():
     """The documented limits of the drop-in are an explicit error contract, raised BEFORE any GPU work:
     the HIP decoder serves Polar(1024, K)+CRC-8 for every K (the reference's detector instantiates 448 only, rtwm/polar_fast.py:18-24)
-    and the detector fs_target = 48 000 (rtwm/detector.py:27).  Constructing such objects works, as in the reference."""
+    and the detector any fs_target whose matched filters fit 576 taps (44 100 Hz and up; rtwm/detector.py:27).  Constructing such objects works,
+    as in the reference."""
     from rtwm.fastpolar import PolarCode
     from rtwm.detector import WatermarkDetector
     with pytest.raises(ValueError):                                            # as in the reference: the reliability table has 1024 entries
@@ -118,12 +119,12 @@ def test_declared_limits_raise_not_implemented():
         assert pc.encode(np.zeros(k - crc, np.uint8)).shape == (n,)
     with pytest.raises(NotImplementedError, match="CRC-8"):                    # (the reference's own encode / decode only work with crc_size 8)
         PolarCode(1024, 448, crc_size=16).decode(np.ones(1024))
-    det = WatermarkDetector(bytes(32), fs_target=44_100)
+    det = WatermarkDetector(bytes(32), fs_target=44_100)                       # any rate the band plan admits is served (GPU tests): 550 taps here
     assert det.fs_target == 44_100
     import torch
     if torch.cuda.is_available():
-        with pytest.raises(NotImplementedError, match="fs_target"):
-            det.verify(np.zeros(5000, np.float32), 44_100)
+        with pytest.raises(NotImplementedError, match="taps"):                 # the 18-22 kHz band within 50 Hz of Nyquist: more than 576 taps
+            WatermarkDetector(bytes(32), fs_target=44_050).verify(np.zeros(5000, np.float32), 44_050)
     # list sizes: any value >= 1 is accepted, as in the reference; the HIP kernels serve up to 256
     assert PolarCode(1024, 448, list_size=3).list_size == 3 and PolarCode(1024, 448, list_size=1000).list_size == 1000
 
