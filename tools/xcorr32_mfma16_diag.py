@@ -35,3 +35,11 @@ for rep in range(3):
     lag = torch.arange(1986, device=bad.device)[None, :].expand_as(bad)[bad]
     print(v, "rep", rep, "bad lags", int(bad.sum()), "records", int(bad.any(dim=1).sum()), "typical rel err", float(d[~bad].max()),
           "tile", torch.bincount((lag % 1024) // 256, minlength=4).tolist(), "lag%16", torch.bincount(lag % 16, minlength=16).tolist(), flush=True)
+    if rep == 0 and int(bad.sum()):
+        rec = torch.arange(B, device=bad.device)[:, None].expand_as(bad)[bad]
+        r0 = int(rec[0]); lags = lag[rec == r0]
+        print("record", r0, "bad lags", lags.tolist()[:40])
+        for L in lags.tolist()[:6]:
+            val = float(c[r0, L]); near = (ref[r0] - val).abs() / ref[r0].abs()
+            print("  lag", L, "got", val, "want", float(ref[r0, L]), "ratio", val / float(ref[r0, L]), "closest reference lag in the record:", int(near.argmin()), float(near.min()),
+                  "neighbours got/want", [(round(float(c[r0, L + d]), 4), round(float(ref[r0, L + d]), 4)) for d in (-2, -1, 1, 2)])
