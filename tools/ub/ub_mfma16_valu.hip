@@ -1,8 +1,9 @@
 // reproducer attempt for the float16-pair experiment (xcorr32_mfma16_experiment.hip.txt): do vector results computed in a wave that also
 // issues v_mfma_f32_16x16x32_f16 change from launch to launch?  Each wave stages 1 088 pseudo-random samples in LDS (padded rows, as the
 // correlation kernel does), forms the 16 window energies per lane (head + core + tail: v_fma_f32 / v_pk_fma_f32 / v_pk_add_f32 chains), and,
-// in the MFMA build, runs 36 float16 matrix instructions on float16 copies of the same samples before / after.  Energies and accumulators go
-// to global memory; the host launches each build three times and counts words that differ between launches and between the builds.
+// in the MFMA build, runs 36 float16 matrix instructions on float16 copies of the same samples before / after.  The factors 1/sqrt(energy) go
+// through the experiment's LDS exchange (owner layout -> accumulator layout -> in-place write-back -> lane order), then factors and accumulators
+// go to global memory; the host launches each build three times and counts words that differ between launches and between the builds.
 //   hipcc -O3 --offload-arch=gfx950 -o ub_mfma16_valu tools/ub/ub_mfma16_valu.hip && ./ub_mfma16_valu
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -120,9 +121,21 @@ void k(const float* __restrict__ y, long long n_items, float* __restrict__ en_ou
         for (int r = 0; r < 16; ++r) fac[r] = __builtin_amdgcn_rsqf(en[r]);
         if (MODE == 2) matrix();
         wave_fence_lds();
+        // the exchange of the experiment: owner layout (lane a, lag r at 20 a + r) -> accumulator layout (tile t, lane (q, c): lags 256 t + 16 c + 4 q + 0..3)
+        // through the LDS words of the samples, products written back in place, fetched again in lane order
         #pragma unroll
-        for (int r = 0; r < 16; r += 4)
-            *reinterpret_cast<f32x4*>(en_out + (long long)item * 1024 + 16 * lane + r) = f32x4{fac[r], fac[r + 1], fac[r + 2], fac[r + 3]};
+        for (int r = 0; r < 16; r += 4) *reinterpret_cast<f32x4*>(s + ROW * lane + r) = f32x4{fac[r], fac[r + 1], fac[r + 2], fac[r + 3]};
+        wave_fence_lds();
+        #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4* fp = reinterpret_cast<f32x4*>(s + 16 * ROW * t + ROW * c + 4 * q);
+            const f32x4 f = *fp;
+            *fp = f32x4{f[0] * 0.5f, f[1] * 0.5f, f[2] * 0.5f, f[3] * 0.5f};
+        }
+        wave_fence_lds();
+        #pragma unroll
+        for (int t = 0; t < 4; ++t)
+            *reinterpret_cast<f32x4*>(en_out + (long long)item * 1024 + 256 * t + 4 * lane) = *reinterpret_cast<const f32x4*>(s + 16 * ROW * t + 4 * lane + 4 * (lane >> 2));
         #pragma unroll
         for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(acc_out + (long long)item * 1024 + 256 * t + 4 * lane) = acc[t];
         wave_fence_lds();
