@@ -88,6 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--c4-chunk", type=int, default=65536)
     ap.add_argument("--c5-frames", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: initialise the process group (RCCL for --backend nccl) at world size 1 and run every collective of the N > 1 "
+                         "path (schedule broadcast, barrier, all_reduce) through it -- lets one GPU load librccl and exercise the calls")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on fewer GPUs)")
     return ap.parse_args(argv)
 
@@ -109,6 +112,8 @@ def launch_ranks(a, *, poll_s: float = 0.05) -> int:
         port = s.getsockname()[1]
     procs = []
     for r in range(a.gpus):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports only dmabuf IPC; with the legacy mode RCCL's (and torch's)
+        # cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it; a caller's own value wins.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -201,25 +206,34 @@ def run_rank(a) -> None:
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and local >= ndev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) are visible")
-    if world > 1:
+    if a.force_collectives and world != 1:
+        raise SystemExit("--force-collectives is for N = 1 (N > 1 runs the collectives anyway)")
+    use_dist = world > 1 or a.force_collectives               # the collective code path: every N > 1 run, or N = 1 on request
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
     if a.backend != "nccl":
         local = local % max(1, ndev)                           # rehearsal: several ranks may share a GPU
-        if world > 1:
+        if use_dist:
             dist.init_process_group(a.backend, rank=rank, world_size=world)       # (the rendezvous needs no device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and a.backend == "nccl":
+    if use_dist and a.backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    collectives = {"broadcast": 0, "barrier": 0, "all_reduce": 0}
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(); collectives["barrier"] += 1
         torch.cuda.synchronize()
 
     def max_over_ranks(dt: float) -> float:
-        if world > 1:
+        if use_dist:
+            collectives["all_reduce"] += 1
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -254,8 +268,8 @@ def run_rank(a) -> None:
         p, b = eng.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=total)
         sched[:, :152] = p; sched[:, 152] = b
         del p, b
-    if world > 1:
-        dist.broadcast(sched, src=0)
+    if use_dist:
+        dist.broadcast(sched, src=0); collectives["broadcast"] += 1
     barrier()
     bcast_s = max_over_ranks(time.perf_counter() - tb)
     pn3, band3 = split_schedule(sched, lo, hi)
@@ -418,6 +432,7 @@ def run_rank(a) -> None:
         frames_h = tx.make_frames(ctrs, synthetic_payloads(tx.sec, ctrs))       # each rank synthesises its own frames (host embedder)
         sched2 = build_schedule(KEY, range(tot2)) if rank == 0 else None
         sched2_d = broadcast_schedule(sched2, tot2, dev)
+        collectives["broadcast"] += int(use_dist)
         pn_d, band_d = split_schedule(sched2_d, lo2, hi2)
         frames_d = torch.from_numpy(frames_h).to(dev)
     if "c2" in legs:
@@ -494,8 +509,8 @@ def run_rank(a) -> None:
             p, b = eng.schedule(tx.sec._prng.sub_key, KEY, ctr0=0, n=T4)
             sched4[:, :152] = p; sched4[:, 152] = b
             del p, b
-        if world > 1:
-            dist.broadcast(sched4, src=0)
+        if use_dist:
+            dist.broadcast(sched4, src=0); collectives["broadcast"] += 1
         barrier()
         bcast4_s = max_over_ranks(time.perf_counter() - tb4)
         pn4, band4 = split_schedule(sched4, lo4, hi4)
@@ -532,8 +547,8 @@ def run_rank(a) -> None:
         cks = (((payload4.to(torch.int64) * w).sum(1) + 1000 * ok4.to(torch.int64) + 7 * peak4.to(torch.int64)) * (idx % 65521 + 1)).sum().reshape(1)
         good = (peak4 == 0).sum().reshape(1)
         bad = (ok4 == -2).sum().reshape(1)
-        if world > 1:
-            dist.all_reduce(cks); dist.all_reduce(good); dist.all_reduce(bad)
+        if use_dist:
+            dist.all_reduce(cks); dist.all_reduce(good); dist.all_reduce(bad); collectives["all_reduce"] += 3
         if int(bad.item()):
             raise SystemExit("c4: list decoder reported undecoded records")
         out_legs["c4"] = {"workload": f"C4: {T4} clean 1215-sample frames in total (ctr 0..{T4 - 1}, generated on the device), sharded contiguously over "
@@ -561,7 +576,8 @@ def run_rank(a) -> None:
                                    f"interpolation, uniform offset, AWGN at -15 dB SNR; generated on the device); band-pass -> float32 NCC screen + exact median/MAD "
                                    f"threshold + NMS / top-5 (one fused kernel) -> _llr(variant 0) at the detected peak -> SCL-{L} (validator None) -> selection",
                        "windows_per_gpu_per_step": Bw, "window_len": 2048, "list_size": L, "frame_len": 1215, "fs": 48000,
-                       "world_size": world, "backend": ("nccl (RCCL)" if a.backend == "nccl" else a.backend) if world > 1 else "none (single rank)",
+                       "world_size": world, "backend": ("nccl (RCCL)" if a.backend == "nccl" else a.backend) if use_dist else "none (single rank)",
+                       "collectives_issued": dict(collectives, process_group=bool(use_dist)),
                        "sharding": f"{world} x {Bw} windows per step (rank r: counters [r*{Bw}, (r+1)*{Bw})); schedule of all {total} counters derived on rank 0, "
                                    f"one broadcast before the timed region ({total * 153} B, {bcast_s:.4f} s incl. derivation)",
                        "pipelining": f"steps rotate over {a.big_lanes} pipeline lanes (HIP streams, one context each): the front ends of some steps run beside the "
@@ -592,7 +608,7 @@ def run_rank(a) -> None:
         if win_h is not None:
             out["cpu_baseline"] = cpu_baseline(win_h, band_h, pn_h, L, start="peak", what=f"of the {Bw} headline windows (2048 samples each)")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

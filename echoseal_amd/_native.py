@@ -14,6 +14,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libechoseal_hip.so")
 
+ES_ABI_VERSION = 2          # include/echoseal_hip.h; load() refuses a library built from another one
 ES_FRAME_LEN = 1215
 ES_PRE_L = 63
 ES_NBANDS = 4
@@ -82,6 +83,14 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C echoseal_amd/csrc`.  There is no CPU fallback for the EchoSeal hot path.")
     lib = ctypes.CDLL(LIB_PATH)
+    try:
+        lib.es_abi_version.restype = c_int
+        got = int(lib.es_abi_version())
+    except AttributeError:
+        got = None
+    if got != ES_ABI_VERSION:
+        raise NativeError(f"{LIB_PATH} reports ABI version {got}, this package binds version {ES_ABI_VERSION} "
+                          "(table strides and signatures differ between versions): rebuild it with `make -C echoseal_amd/csrc`")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here means header and library disagree
         fn.restype = res

@@ -54,7 +54,7 @@ int es_cursor_next(es_ctx* ctx, int** cursor)
 
 extern "C" {
 
-int es_abi_version(void) { return 1; }
+int es_abi_version(void) { return ES_ABI_VERSION; }
 
 int es_info_bytes(const es_ctx* ctx) { return (ctx && ctx->n_info >= 9) ? (ctx->n_info - 8 + 7) / 8 : ES_INFO_BYTES; }
 

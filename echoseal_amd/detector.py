@@ -21,7 +21,7 @@ from .crypto import SecureChannel
 from .polar_fast import N_DEFAULT
 from .primitives import InvalidTag
 from .tables import matched_filter_taps
-from .utils import BAND_PLAN, butter_bandpass, choose_band, mseq_63, resample_to  # noqa: F401 (re-exported)
+from .utils import BAND_PLAN, BandHop, butter_bandpass, choose_band, mseq_63, resample_to  # noqa: F401 (re-exported)
 
 PRE_BITS = mseq_63()
 PRE_L = len(PRE_BITS)
@@ -45,6 +45,7 @@ class WatermarkDetector:
         self.fs_target = fs_target
         self.session_nonce: bytes | None = None
         self._band_key = getattr(self.sec, "band_key", key32)
+        self._hop = BandHop(self._band_key)                 # choose_band(self._band_key, .) memoised for the life of this detector
         self._mf_cache: dict = {}
         self._list_size = int(list_size)
         self._aead = getattr(self.sec, "_aead", None)
@@ -97,7 +98,7 @@ class WatermarkDetector:
         return signal
 
     def _band_order(self):
-        hop0 = choose_band(self._band_key, 0)
+        hop0 = self._hop.band(0)
         return [hop0] + [b for b in BAND_PLAN if b != hop0]                 # rtwm/detector.py:46-52
 
     def verify(self, audio: np.ndarray, fs_in: int) -> bool:
@@ -212,15 +213,15 @@ class WatermarkDetector:
             cands: list[int] = []
             if hdr_ok:                                                      # rtwm/detector.py:122-127
                 for ctr in range(max(0, ctr_est - WIDE_DELTA), ctr_est + WIDE_DELTA + 1):
-                    if (ctr & 0xFFFF) == ctr_lo16 and choose_band(self._band_key, ctr) == band:
+                    if (ctr & 0xFFFF) == ctr_lo16 and self._hop.band(ctr) == band:
                         cands.append(ctr)
             else:                                                           # :131-140
                 for ctr in range(max(0, ctr_est - TIGHT_DELTA), ctr_est + TIGHT_DELTA + 1):
-                    if choose_band(self._band_key, ctr) == band:
+                    if self._hop.band(ctr) == band:
                         cands.append(ctr)
                 if not cands:
                     for ctr in range(max(0, ctr_est - WIDE_DELTA), ctr_est + WIDE_DELTA + 1):
-                        if choose_band(self._band_key, ctr) == band:
+                        if self._hop.band(ctr) == band:
                             cands.append(ctr)
             for ctr in cands[:MAX_TRIES - tried]:
                 plan.append((j, start, ctr, len(hdr_log) - 1))              # (.., index of this peak's header decode in hdr_log)
@@ -255,11 +256,11 @@ class WatermarkDetector:
         signal = np.asarray(signal)
         if len(signal) == FRAME_LEN:
             for ctr in range(4):
-                band = choose_band(self._band_key, ctr)
+                band = self._hop.band(ctr)
                 y = self._bandpass(signal, band)
                 if self._try_decode_frame(y, ctr):
                     return True
-        return self._scan_band_multi_frame(signal, choose_band(self._band_key, 0))
+        return self._scan_band_multi_frame(signal, self._hop.band(0))
 
     def _scan_band(self, signal: np.ndarray, band, skip_filtering: bool = False) -> bool:
         return self._scan_band_multi_frame(signal, band)
@@ -311,7 +312,7 @@ class WatermarkDetector:
         frame = np.asarray(frame, dtype=np.float64).reshape(-1)
         if frame.size == 0:
             return np.zeros(N_DEFAULT, dtype=np.float32)
-        band = choose_band(self._band_key, frame_id)
+        band = self._hop.band(frame_id)
         y = self._dev(frame.reshape(1, -1), np.float64)
         out = self.engine.llr(y, self._dev(np.array([self._band_id(band)]), np.uint8),
                               self._dev(self._pn_rows([frame_id]), np.uint8), variant=int(pn_variant))

@@ -37,7 +37,7 @@ def build_schedule(key32: bytes, ctrs) -> np.ndarray:
 def broadcast_schedule(schedule: np.ndarray | None, n_total: int, device: torch.device, src: int = 0) -> torch.Tensor:
     """Root passes the [n_total, 153] schedule, peers pass None; everyone gets the device tensor."""
     buf = torch.empty((n_total, ROW), dtype=torch.uint8, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():             # (a world of one included: the same calls, trivially)
         if dist.get_rank() == src:
             buf.copy_(torch.from_numpy(np.ascontiguousarray(schedule)))
         dist.broadcast(buf, src=src)
@@ -57,7 +57,7 @@ def broadcast_keys(keys48: bytes | None, device: torch.device, src: int = 0) -> 
     (16-byte AES PN sub-key | 32-byte hop key), peers pass None; every rank then derives the rows of its own shard
     on its GPU with `RxEngine.schedule` (es_schedule_batch).  One 48-byte broadcast instead of 153 B per counter."""
     buf = torch.zeros(48, dtype=torch.uint8, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():             # (a world of one included: the same calls, trivially)
         if dist.get_rank() == src:
             buf.copy_(torch.frombuffer(bytearray(keys48), dtype=torch.uint8))
         dist.broadcast(buf, src=src)

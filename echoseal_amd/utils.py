@@ -8,7 +8,6 @@ kernels consume.  The AES / HMAC code is our own (echoseal_amd.primitives) becau
 """
 from __future__ import annotations
 
-import functools
 import hashlib
 import hmac
 import math
@@ -27,16 +26,32 @@ BAND_PLAN: list[Tuple[int, int]] = [
 ]
 
 
-@functools.lru_cache(maxsize=1 << 18)
-def _band_index_cached(key: bytes, frame_ctr: int) -> int:
-    tag = hmac.new(key, frame_ctr.to_bytes(4, "big"), hashlib.sha256).digest()
+def band_index(key: bytes, frame_ctr: int) -> int:
+    """Index into BAND_PLAN for a frame counter: HMAC-SHA256(key, ctr_be32)[0] mod 4 (rtwm/utils.py:27-36).  Not memoised here: a
+    process-wide cache would keep the secret hop key alive after its detector is gone (see BandHop)."""
+    tag = hmac.new(bytes(key), int(frame_ctr).to_bytes(4, "big"), hashlib.sha256).digest()
     return tag[0] % len(BAND_PLAN)
 
 
-def band_index(key: bytes, frame_ctr: int) -> int:
-    """Index into BAND_PLAN for a frame counter: HMAC-SHA256(key, ctr_be32)[0] mod 4.  (Memoised: the counter search of one verify() asks
-    for several hundred counters, the same ones clip after clip -- 2 ms of HMACs per call on the host otherwise.)"""
-    return _band_index_cached(bytes(key), int(frame_ctr))
+class BandHop:
+    """The hop schedule of ONE key, memoised per owner: the counter search of one verify() asks for several hundred counters, the same
+    ones clip after clip (2 ms of HMACs per call on the host otherwise).  Lives and dies with the object that owns it (a
+    WatermarkDetector), holds at most `limit` counters, and never leaves key material in module state."""
+
+    def __init__(self, key: bytes, limit: int = 1 << 16) -> None:
+        self._key, self._limit, self._memo = bytes(key), int(limit), {}
+
+    def index(self, frame_ctr: int) -> int:
+        c = int(frame_ctr)
+        v = self._memo.get(c)
+        if v is None:
+            if len(self._memo) >= self._limit:
+                self._memo.clear()
+            v = self._memo[c] = band_index(self._key, c)
+        return v
+
+    def band(self, frame_ctr: int) -> tuple[int, int]:
+        return BAND_PLAN[self.index(frame_ctr)]
 
 
 def choose_band(key: bytes, frame_ctr: int) -> tuple[int, int]:

@@ -24,6 +24,11 @@
 extern "C" {
 #endif
 
+/* Version of this ABI.  2 (round 4): the tap table of es_set_tables has a row stride of ES_MAX_TAPS = 576 floats (1: 160), the
+ * `nflag` parameters are gone, es_info_bytes / es_front_batch exist.  A binder must compare es_abi_version() with the ES_ABI_VERSION it
+ * was written against and refuse a mismatch (echoseal_amd/_native.py:load does; the stub in INTEGRATION.md does). */
+#define ES_ABI_VERSION   2
+
 #define ES_OK            0
 #define ES_EINVAL      (-1)   /* bad argument (shape, list size, null pointer) */
 #define ES_ENOTREADY   (-2)   /* tables / schedule not set */
@@ -55,7 +60,7 @@ typedef struct es_ctx es_ctx;
 es_ctx*     es_create(int device, int list_size_max);
 void        es_destroy(es_ctx* ctx);
 const char* es_last_error(const es_ctx* ctx);          /* ctx may be NULL (creation errors) */
-int         es_abi_version(void);
+int         es_abi_version(void);                      /* == ES_ABI_VERSION of the header the library was built from */
 int         es_info_bytes(const es_ctx* ctx);          /* bytes of one packed information row of es_scl_batch: 55, or ceil((K - 8) / 8) after es_set_tables with another K */
 
 /* Static per-band tables (host pointers).

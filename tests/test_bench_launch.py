@@ -64,3 +64,31 @@ def test_two_rank_rehearsal_and_checksum_independent_of_world_size():
     assert j2["legs"]["c4"]["frames_per_rank"] == 8192 and j2["legs"]["c4"]["scaling"] == "strong"
     assert j1["legs"]["c4"]["checksum"] == j2["legs"]["c4"]["checksum"]
     assert j1["legs"]["c4"]["frames_with_sync_offset_0"] == j2["legs"]["c4"]["frames_with_sync_offset_0"] == 16384
+
+
+def _forced(backend, extra=()):
+    return subprocess.run([sys.executable, BENCH, "--gpus", "1", "--backend", backend, "--force-collectives", "--steps", "2", "--warmup", "1",
+                           "--windows", "4096", "--legs", "c2,c4", "--c2-steps", "20", "--c4-frames", "8192", "--c4-chunk", "4096", "--no-cpu-baseline",
+                           *extra], env=_env(), capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.gpu
+def test_rccl_runs_once_at_world_size_one():
+    """RCCL (backend "nccl") must have run here before the driver's 8-GPU box runs it: a fresh process (nothing in this one has to touch
+    the GPU for it) goes through bench.py's whole collective code path at world size 1 -- init_process_group("nccl", device_id=...), the
+    schedule broadcasts of the headline and of legs c2 / c4, the barriers, the float64 all_reduce(MAX) of the timing and the int64
+    all_reduces of the c4 checksum -- and must agree with the run that issues no collective at all."""
+    forced = _forced("nccl")
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    j = json.loads(forced.stdout.strip().splitlines()[-1])
+    c = j["config"]["collectives_issued"]
+    assert j["n_gpus"] == 1 and j["config"]["backend"] == "nccl (RCCL)" and c["process_group"]
+    assert c["broadcast"] >= 3 and c["barrier"] >= 10 and c["all_reduce"] >= 6, c
+    assert j["config"]["results_identical_to_a_sequential_pass"] and j["legs"]["c2"]["sync_offsets_ok"]
+    plain = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--windows", "4096", "--legs", "c4",
+                            "--c4-frames", "8192", "--c4-chunk", "4096", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    j0 = json.loads(plain.stdout.strip().splitlines()[-1])
+    assert not j0["config"]["collectives_issued"]["process_group"] and j0["config"]["backend"] == "none (single rank)"
+    assert j0["legs"]["c4"]["checksum"] == j["legs"]["c4"]["checksum"]
+    assert j0["legs"]["c4"]["frames_with_sync_offset_0"] == j["legs"]["c4"]["frames_with_sync_offset_0"] == 8192

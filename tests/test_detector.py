@@ -83,6 +83,57 @@ def test_verify_follows_reference_search(engine):
 
 
 @pytest.mark.gpu
+def test_quick_roundtrip_frame_at_list32_follows_reference(engine):
+    """BASELINE config 1 exactly as the reference writes it (tests/test_roundtrip_quick.py:5-15): one synthesised frame through
+    WatermarkDetector(key, list_size=32).verify_raw_frame.  tests/golden/quick32.npz holds the reference's own run: the result
+    (False: SURVEY section 0.2), the counters handed to _try_decode_frame in order (four direct tries, rtwm/detector.py:235-245, then the
+    scan's), the scan's (band, peak, counter) trace, the 20 LLR vectors it decoded with the blob each decode returned under the
+    AEAD validator, and the validator-free PolarCode.decode(list_size=32) of each of those vectors."""
+    import torch
+    from echoseal_amd.embedder import WatermarkEmbedder
+    from echoseal_amd.engine import select_payload
+    g = np.load(os.path.join(GOLD, "quick32.npz"))
+    L = int(g["list_size"])
+    tx = WatermarkEmbedder(KEY)
+    frame = tx.make_frames([0], [bytes(range(55))])[0]
+    assert np.array_equal(frame, g["frame"])                               # our embedder == the reference's on the quick-test frame
+    det = WatermarkDetector(KEY, list_size=L, engine=engine)
+    det._trace = []
+    tried, decoded = [], []
+    real_try, real_pairs = det._try_decode_frame, det._decode_pairs_chunk
+    det._try_decode_frame = lambda fr, ctr: (tried.append(int(ctr)), real_try(fr, ctr))[1]
+
+    def pairs(frames, rows, ctrs):
+        out = real_pairs(frames, rows, ctrs)
+        decoded.extend((int(c), blobs) for c, blobs in zip(ctrs, out))
+        return out
+    det._decode_pairs_chunk = pairs
+    assert det.verify_raw_frame(g["frame"]) == bool(g["result"])
+    assert det.session_nonce is None and g["session_nonce"].size == 0
+    # four direct tries through _try_decode_frame, then the scan decodes its candidates in one batch (the same counters, in order)
+    assert tried == list(g["tried"][:4]) and [c for c, _ in decoded] == list(g["tried"])
+    assert np.array_equal(np.array(det._trace, dtype=np.int64).reshape(-1, 3), g["scan_trace"])
+    blobs = [b for _, four in decoded for b in four]                       # the reference's decode order: per counter +llr0, -llr0, +llr1, -llr1
+    assert len(blobs) == g["blob_ok"].size
+    for k, b in enumerate(blobs):
+        assert (b is not None) == bool(g["blob_ok"][k]) and (b is None or b == g["blob"][k].tobytes()), k
+    # the demodulator on the quick-test frame: the LLR vectors the reference decoded (bar 1e-5), in its order
+    k = 0
+    for ctr in g["tried"][:4]:
+        y = det._bandpass(g["frame"], __import__("echoseal_amd.utils", fromlist=["choose_band"]).choose_band(det._band_key, int(ctr)))
+        for variant in (0, 1):
+            llr = det._llr(y, int(ctr), variant)
+            for sign in (1.0, -1.0):
+                assert np.max(np.abs(sign * llr - g["llr"][k])) <= 1e-5, (k, ctr, variant)
+                k += 1
+    # the list decoder at L = 32 on the reference's own LLR vectors, validator-free: (info, ok) exact
+    res = engine.scl(torch.from_numpy(g["llr"]).to(engine.device), list_size=L, skip_if_hard_ok=True)
+    for k in range(g["llr"].shape[0]):
+        payload, ok = select_payload(res, k, None)
+        assert ok == bool(g["plain_ok"][k]) and payload == g["plain_info"][k].tobytes(), k
+
+
+@pytest.mark.gpu
 def test_try_decode_frame_true_positive(engine):
     """The reference's DSP cannot produce a decodable frame, so feed the decoder
     a frame whose LLRs are clean: monkey-patch the demodulator stage only, keep polar+AEAD real."""

@@ -35,7 +35,7 @@ def _dev(eng, *arrs):
 
 def test_native_library_is_loaded(engine):
     import echoseal_amd._native as nat
-    assert nat.load().es_abi_version() == 1
+    assert nat.load().es_abi_version() == nat.ES_ABI_VERSION == 2
 
 
 def test_pipeline_bit_exact_vs_oracle(engine, oracle):

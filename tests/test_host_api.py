@@ -19,9 +19,23 @@ def test_header_and_library_agree():
     lib = ctypes.CDLL(nat.LIB_PATH)                       # loads without a GPU; no compute calls here
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.es_abi_version() == 1
+    assert lib.es_abi_version() == nat.ES_ABI_VERSION == int(re.search(r"#define\s+ES_ABI_VERSION\s+(\d+)", hdr).group(1)) == 2
     for const, val in (("ES_FRAME_LEN", 1215), ("ES_MAX_TAPS", 576), ("ES_MAX_TAPS_FAST", 160), ("ES_MAX_PEAKS", 32), ("ES_PN_BYTES", 152)):
         assert int(re.search(rf"#define\s+{const}\s+(\d+)", hdr).group(1)) == val == getattr(nat, const)
+
+
+def test_loader_refuses_another_abi_version(tmp_path, monkeypatch):
+    """A library built from an older header (ABI 1: 160-float tap rows) must not be bound: _native.load() raises instead."""
+    import subprocess
+    import echoseal_amd._native as nat
+    src = tmp_path / "stale.c"
+    src.write_text("int es_abi_version(void) { return 1; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    monkeypatch.setattr(nat, "LIB_PATH", str(so))
+    monkeypatch.setattr(nat, "_lib", None)
+    with pytest.raises(nat.NativeError, match="ABI version 1"):
+        nat.load()
 
 
 def test_product_never_imports_oracle():

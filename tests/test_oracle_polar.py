@@ -6,6 +6,7 @@ in the penalty), `glibc` = NumPy forced onto the C library.  Decoded bits must a
 path metrics agree bit-for-bit in glibc mode and to a few ulp in default mode.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -107,3 +108,14 @@ def test_wide_lists_match_reference(oracle, mode):
                 n, ci, cm, cc = oracle.scl_list(g[f"{name}/llr"], L)
                 assert np.array_equal(np.packbits(ci, axis=1), g[f"{name}/L{L}/cand_info"])
                 assert np.array_equal(cm, g[key]) if mode == "glibc" else np.allclose(cm, g[key], rtol=1e-13, atol=0)
+
+
+def test_quick_frame_list32_decodes_match_reference(oracle):
+    """BASELINE config 1 at the list size the reference's own test uses (tests/test_roundtrip_quick.py:14): the 20 LLR vectors the
+    reference's verify_raw_frame handed to polar decode on the quick-test frame (tests/golden/quick32.npz, generator
+    oracle/refshim/gen_golden_quick32.py), decoded by PolarCode.decode(list_size=32) without a validator: (info, ok) bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quick32.npz"))
+    assert int(g["list_size"]) == 32 and g["llr"].shape == (20, 1024) and (g["dec_list_size"] == 32).all()
+    for k in range(g["llr"].shape[0]):
+        info, ok, _took = oracle.polar_decode(g["llr"][k], 32)
+        assert ok == bool(g["plain_ok"][k]) and np.array_equal(np.packbits(info), g["plain_info"][k]), k
