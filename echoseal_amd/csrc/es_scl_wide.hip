@@ -40,6 +40,7 @@
 // which lets es_math.h address its entries without adding a base.
 #define ES_EXP_TAB_LDS_ADDR 0u
 #include "es_scl_common.h"
+#include <type_traits>
 #ifndef ES_WIDE_GBATCH
 #define ES_WIDE_GBATCH 8                          /* load pairs in flight in the lane-serial g loops (divides 8; 8: +1 % over 4, measured) */
 #endif
@@ -58,6 +59,9 @@
 #endif
 #ifndef ES_WIDE_FDIST
 #define ES_WIDE_FDIST 2                           /* f loops: operand pairs requested this many f evaluations ahead (1: rotation by copy; 2: unrolled by three) */
+#endif
+#ifndef ES_WIDE_LDS_DEPTH
+#define ES_WIDE_LDS_DEPTH 7                       /* one-wave blocks: first LLR-tree depth kept in LDS (7: 8 + 4 + 2 rows of doubles by slot; 8: round 3's layout; 6 needs two waves per SIMD) */
 #endif
 
 namespace {
@@ -85,23 +89,42 @@ constexpr int MWIN_MAX = N / 32;              // ... of any code (GK instantiati
 // aux slab per path: windows 32 x (4 + 2) B (14 used by the default code), partial-sum blocks of 128 / 256 / 512 bits 28 x 4 B, fold scratch 16 x 4 B
 constexpr int WIDE_AUX_PER_PATH = MWIN_MAX * 6 + 28 * 4 + 16 * 4;
 
-// NB = 2: buffers that a wave may still be reading while another wave is already a sort further (several waves per frame);
-// a block that is one wave runs in order and needs one of each.
+// LLR-tree depths DL..9 live in LDS, [element][slot]: depth d at rows [wide_low_row(DL, d), +1024 >> d).  A block that is one wave keeps depth 7
+// there too (DL = 7: a step whose top is depth 7 or below then touches the slab only to READ depth 6, and the values that are written and
+// read back within a few hundred cycles never leave the CU); blocks of several waves hold a frame of 128 / 256 paths and have no LDS to spare.
+constexpr int wide_dl(bool one_wave) { return one_wave ? ES_WIDE_LDS_DEPTH : 8; }
+constexpr int wide_low_row(int DL, int d) { int r = 0; for (int k = DL; k < d; ++k) r += N >> k; return r; }
+
+// What follows a path through a sort.  Several waves per frame (NB = 2: double-buffered by information index, a wave may still be reading
+// while another is a sort further): every path publishes it to LDS and the survivor of rank r reads its parent's.  ONE wave per block
+// (NB = 1): nothing is stored -- the survivor fetches its parent's registers with ds_bpermute (the lanes of a wave run in lock step).
 template <int L, int NB>
-struct WideLds {
-    uint64_t exp_tab[ES_EXP_TAB_WORDS];
-    double   low[6][L];                 // depth 8 (rows 0..3) and depth 9 (rows 4, 5), by slot
+struct WidePub {
     double   skey[NB][2 * L];           // cross-wave sort stages and the read-out
-    double   xsp[NB][2][L];             // published at a sort (NB = 2: double-buffered by information index): softplus pair,
+    double   xsp[NB][2][L];             // softplus pair of the even sibling,
     uint64_t xpa[NB][L];                // ... LLR-tree slot pointers,
     uint64_t xpb[NB][L];                // ... partial-sum slot pointers | depth-9 pointer << 40 | window ancestor << 48,
     uint32_t xb0[NB][L];                // ... partial sums of 1..16 bits,
     uint32_t xhist[NB][L];              // ... bits of the current trace-back window
-    uint32_t betaM[3][L];               // partial-sum blocks of 32 (row 0) and 64 bits (1, 2), by slot (wider ones, touched a few times per frame: slab)
     uint16_t sidx[NB][2 * L];
+};
+#ifndef ES_WIDE_GATHER_BPERM
+#define ES_WIDE_GATHER_BPERM 1                    /* one-wave blocks: survivors take their parent's state with ds_bpermute (0: through LDS, as blocks of several waves do) */
+#endif
+#if ES_WIDE_GATHER_BPERM
+template <int L> struct WidePub<L, 1> { };
+#endif
+
+template <int L, int NB>
+struct WideLds {
+    static constexpr int DL = wide_dl(NB == 1);
+    static constexpr int NLOW = wide_low_row(DL, 10);
+    uint64_t exp_tab[ES_EXP_TAB_WORDS];
+    double   low[NLOW][L];              // depths DL..9, by slot (also: the hard decision's 184 bytes and the final ordering's metrics, outside the list loop)
+    uint32_t betaM[3][L];               // partial-sum blocks of 32 (row 0) and 64 bits (1, 2), by slot (wider ones, touched a few times per frame: slab)
     int      fr[64];                    // frames drawn from the cursor (up to 64 per one-wave block)
     int      flag;
-    // (the hard decision's 184 bytes borrow the first wave's cells of skey[0])
+    WidePub<L, NB> pub;
 };
 
 __device__ __forceinline__ uint64_t p8_set(uint64_t w, int k, int v) { const int sh = 8 * k; return (w & ~(255ULL << sh)) | ((uint64_t)(uint32_t)v << sh); }
@@ -142,7 +165,9 @@ __device__ __forceinline__ bool cand_before(double ka, uint32_t ia, double kb, u
 // partner - mine (the modified operand is the minuend; tools/ub/ub_dppvcc.hip), so VCC = "the partner sorts before mine" and keeping
 // mine is VCC xor take_min (equal elements are two dead lanes' identical fillers: either may be kept).  (s_nop 1: a DPP operand must
 // not have been written by the two preceding vector instructions; the compiler cannot see into the block.)  tools/ub/ub_sortce.hip
-// checks every step form against plain C++.
+// checks every step form against plain C++.  The scalar xor / xnor of the mask also writes SCC: it is in the clobber list ("scc") -- without
+// it the compiler kept a scalar compare's result live across a step (round 4: `info_idx % 32 == 0` evaluated before the sort and selected
+// on after it came out wrong in the 64-path instantiation, whose scheduling happened to put the compare there).
 #define ES_CE_DPP(CTRL, lo, hi, ix, tmask)                                                                                   \
     do { uint32_t t_;                                                                                                        \
         asm volatile("s_nop 1\n\t"                                                                                           \
@@ -153,7 +178,7 @@ __device__ __forceinline__ bool cand_before(double ka, uint32_t ia, double kb, u
                      "v_cndmask_b32_dpp %2, %2, %2, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                             \
                      "v_cndmask_b32_dpp %0, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                             \
                      "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                                 \
-                     : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "s"(tmask) : "vcc");                                        \
+                     : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "s"(tmask) : "vcc", "scc");                                 \
     } while (0)
 // the partner's words already fetched (ds_swizzle / ds_bpermute / LDS): keep mine where (mine < other) == take_min
 __device__ __forceinline__ void ce_pair(uint32_t& lo, uint32_t& hi, uint32_t& ix, uint32_t olo, uint32_t ohi, uint32_t oix, unsigned long long tmask)
@@ -166,7 +191,7 @@ __device__ __forceinline__ void ce_pair(uint32_t& lo, uint32_t& hi, uint32_t& ix
                  "v_cndmask_b32 %2, %6, %2, vcc\n\t"
                  "v_cndmask_b32 %0, %4, %0, vcc\n\t"
                  "v_cndmask_b32 %1, %5, %1, vcc"
-                 : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "v"(olo), "v"(ohi), "v"(oix), "s"(tmask) : "vcc");
+                 : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "v"(olo), "v"(ohi), "v"(oix), "s"(tmask) : "vcc", "scc");
 }
 // a lane's own two elements: swap where (element 1 < element 0) == ascending
 __device__ __forceinline__ void ce_inlane(uint32_t& lo0, uint32_t& hi0, uint32_t& ix0, uint32_t& lo1, uint32_t& hi1, uint32_t& ix1, unsigned long long amask)
@@ -183,7 +208,7 @@ __device__ __forceinline__ void ce_inlane(uint32_t& lo0, uint32_t& hi0, uint32_t
                  "v_cndmask_b32 %8, %8, %5, vcc\n\t"
                  "v_cndmask_b32 %9, %9, %6, vcc"
                  : "=&v"(nlo0), "=&v"(nhi0), "=&v"(nix0), "=&v"(t_), "+v"(lo0), "+v"(hi0), "+v"(ix0), "+v"(lo1), "+v"(hi1), "+v"(ix1)
-                 : "s"(amask) : "vcc");
+                 : "s"(amask) : "vcc", "scc");
     lo0 = nlo0; hi0 = nhi0; ix0 = nix0;
 }
 #endif
@@ -210,18 +235,23 @@ __device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, 
                 else if (dl == 2) { ES_CE_DPP("quad_perm:[2,3,0,1]", lo0, hi0, i0, tm); ES_CE_DPP("quad_perm:[2,3,0,1]", lo1, hi1, i1, tm); }
                 else if (dl == 8) { ES_CE_DPP("row_ror:8", lo0, hi0, i0, tm); ES_CE_DPP("row_ror:8", lo1, hi1, i1, tm); }
                 else {
-                    uint32_t a0, b0, c0, a1, b1, c1;
-                    if (dl >= 64) {
-                        W.skey[buf][2 * p] = __builtin_bit_cast(double, ((uint64_t)hi0 << 32) | lo0);
-                        W.skey[buf][2 * p + 1] = __builtin_bit_cast(double, ((uint64_t)hi1 << 32) | lo1);
-                        W.sidx[buf][2 * p] = (uint16_t)i0; W.sidx[buf][2 * p + 1] = (uint16_t)i1;
-                        __syncthreads();
-                        const int o = p ^ dl;
-                        const uint64_t x0 = __builtin_bit_cast(uint64_t, W.skey[buf][2 * o]), x1 = __builtin_bit_cast(uint64_t, W.skey[buf][2 * o + 1]);
-                        a0 = (uint32_t)x0; b0 = (uint32_t)(x0 >> 32); a1 = (uint32_t)x1; b1 = (uint32_t)(x1 >> 32);
-                        c0 = W.sidx[buf][2 * o]; c1 = W.sidx[buf][2 * o + 1];
-                        buf ^= 1;
-                    } else {
+                    uint32_t a0 = 0, b0 = 0, c0 = 0, a1 = 0, b1 = 0, c1 = 0;
+                    bool cross = false;
+                    if constexpr (LF > 64) {
+                        if (dl >= 64) {
+                            cross = true;
+                            W.pub.skey[buf][2 * p] = __builtin_bit_cast(double, ((uint64_t)hi0 << 32) | lo0);
+                            W.pub.skey[buf][2 * p + 1] = __builtin_bit_cast(double, ((uint64_t)hi1 << 32) | lo1);
+                            W.pub.sidx[buf][2 * p] = (uint16_t)i0; W.pub.sidx[buf][2 * p + 1] = (uint16_t)i1;
+                            __syncthreads();
+                            const int o = p ^ dl;
+                            const uint64_t x0 = __builtin_bit_cast(uint64_t, W.pub.skey[buf][2 * o]), x1 = __builtin_bit_cast(uint64_t, W.pub.skey[buf][2 * o + 1]);
+                            a0 = (uint32_t)x0; b0 = (uint32_t)(x0 >> 32); a1 = (uint32_t)x1; b1 = (uint32_t)(x1 >> 32);
+                            c0 = W.pub.sidx[buf][2 * o]; c1 = W.pub.sidx[buf][2 * o + 1];
+                            buf ^= 1;
+                        }
+                    }
+                    if (!cross) {
                         a0 = (uint32_t)wxor_b32((int)lo0, dl); b0 = (uint32_t)wxor_b32((int)hi0, dl); c0 = (uint32_t)wxor_b32((int)i0, dl);
                         a1 = (uint32_t)wxor_b32((int)lo1, dl); b1 = (uint32_t)wxor_b32((int)hi1, dl); c1 = (uint32_t)wxor_b32((int)i1, dl);
                     }
@@ -246,16 +276,21 @@ __device__ __forceinline__ void wide_sort(double& k0, uint32_t& i0, double& k1, 
             } else {
                 const int dl = j >> 1;                           // partner lane p ^ dl, same b
                 const bool take_min = (((pl & dl) == 0) == asc);
-                double ok0, ok1; uint32_t oi0, oi1;
-                if (dl >= 64) {
-                    W.skey[buf][2 * p] = k0; W.skey[buf][2 * p + 1] = k1;
-                    W.sidx[buf][2 * p] = (uint16_t)i0; W.sidx[buf][2 * p + 1] = (uint16_t)i1;
-                    __syncthreads();
-                    const int o = p ^ dl;
-                    ok0 = W.skey[buf][2 * o]; ok1 = W.skey[buf][2 * o + 1];
-                    oi0 = W.sidx[buf][2 * o]; oi1 = W.sidx[buf][2 * o + 1];
-                    buf ^= 1;
-                } else {
+                double ok0 = 0, ok1 = 0; uint32_t oi0 = 0, oi1 = 0;
+                bool cross = false;
+                if constexpr (LF > 64) {
+                    if (dl >= 64) {
+                        cross = true;
+                        W.pub.skey[buf][2 * p] = k0; W.pub.skey[buf][2 * p + 1] = k1;
+                        W.pub.sidx[buf][2 * p] = (uint16_t)i0; W.pub.sidx[buf][2 * p + 1] = (uint16_t)i1;
+                        __syncthreads();
+                        const int o = p ^ dl;
+                        ok0 = W.pub.skey[buf][2 * o]; ok1 = W.pub.skey[buf][2 * o + 1];
+                        oi0 = W.pub.sidx[buf][2 * o]; oi1 = W.pub.sidx[buf][2 * o + 1];
+                        buf ^= 1;
+                    }
+                }
+                if (!cross) {
                     ok0 = wxor_f64(k0, dl); ok1 = wxor_f64(k1, dl);
                     oi0 = (uint32_t)wxor_b32((int)i0, dl); oi1 = (uint32_t)wxor_b32((int)i1, dl);
                 }
@@ -421,8 +456,10 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
     auto beta_ld = [&](int wi, int s) -> uint32_t { return wi < 4 ? W.betaM[wi - 1][s] : BG[(wi - 4) * L + s]; };
     auto beta_st = [&](int wi, int s, uint32_t v) { if (wi < 4) W.betaM[wi - 1][s] = v; else BG[(wi - 4) * L + s] = v; };
 
-    uint32_t* const hd_words = reinterpret_cast<uint32_t*>(&W.skey[0][0]);                  // 32 words ...
-    uint8_t* const hd_bytes = reinterpret_cast<uint8_t*>(&W.skey[0][16]);                   // ... and 56 bytes of the hard decision (first wave)
+    constexpr int DL = WLds::DL;                                                             // first LLR-tree depth held in LDS
+    auto lrow = [](int d) constexpr { return wide_low_row(WLds::DL, d); };                   // its first row in W.low
+    uint32_t* const hd_words = reinterpret_cast<uint32_t*>(&W.low[0][0]);                   // 32 words ...
+    uint8_t* const hd_bytes = reinterpret_cast<uint8_t*>(&W.low[0][16]);                    // ... and up to 128 bytes of the hard decision (first wave; the rows are idle outside the list loop)
     const long long n_groups = a.cursor ? (long long)gridDim.x : (a.B + FRG - 1) / FRG;      // (cursor: one draw per block)
     for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {      // one group of FRG frames per block (grid = groups)
         long long f; bool f_valid;
@@ -527,27 +564,29 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
             if (i == 0) {
                 // First chain: the paths of a frame are still copies of its path 0, so each node is computed once, the frame's
                 // lanes sharing its elements, into that path's slot (a barrier per depth here: lanes read what other lanes wrote).
-                for (int d = 1; d <= 7; ++d) {
+                #pragma unroll 1
+                for (int d = 1; d <= 9; ++d) {
                     const int S = N >> d;
+                    const int rs = wide_low_row(DL, d - 1), rd = wide_low_row(DL, d);      // rows of depth d-1 / d when they are in LDS
+                    #pragma unroll 1
                     for (int j = pl; j < S; j += LF) {
                         double pa, pb;
                         if (d == 1) { pa = a.is_f64 ? llr64[j] : (double)llr32[j]; pb = a.is_f64 ? llr64[j + S] : (double)llr32[j + S]; }
-                        else { pa = A[(long long)(2 * S + j) * L + fp0]; pb = A[(long long)(2 * S + j + S) * L + fp0]; }
-                        A[(long long)(S + j) * L + fp0] = es_polar_f(pa, pb, tab);
+                        else if (d <= DL) { pa = A[(long long)(2 * S + j) * L + fp0]; pb = A[(long long)(2 * S + j + S) * L + fp0]; }
+                        else { pa = W.low[rs + j][fp0]; pb = W.low[rs + j + S][fp0]; }
+                        const double v = es_polar_f(pa, pb, tab);
+                        if (d < DL) A[(long long)(S + j) * L + fp0] = v; else W.low[rd + j][fp0] = v;
                     }
                     group_sync();
                 }
-                for (int j = pl; j < 4; j += LF) W.low[j][fp0] = es_polar_f(A[(long long)(8 + j) * L + fp0], A[(long long)(12 + j) * L + fp0], tab);
-                group_sync();
-                for (int j = pl; j < 2; j += LF) W.low[4 + j][fp0] = es_polar_f(W.low[j][fp0], W.low[j + 2][fp0], tab);
-                group_sync();
-                lam = es_polar_f_sp(W.low[4][fp0], W.low[5][fp0], tab, &sp_diff, &sp_sum);
+                lam = es_polar_f_sp(W.low[lrow(9)][fp0], W.low[lrow(9) + 1][fp0], tab, &sp_diff, &sp_sum);
                 dirty = true;
             } else {
                 const int top = NLEV - __builtin_ctz((unsigned)i);
                 if (top <= 9 && dirty) { group_sync(); dirty = false; }         // this step writes slots
-                // --- depths top..7: slab to slab, the lane walks the node
-                for (int d = top; d <= 7; ++d) {
+                // --- depths top..DL-1: slab to slab, the lane walks the node
+                bool have_dl = false;                                               // depth DL already formed (in LDS) by a fused pass of this step
+                for (int d = top; d < DL; ++d) {
                     const int S = N >> d;
                     const bool is_g = (i >> (NLEV - d)) & 1;
                     const int ps = (d > 1) ? p8_get(pa_, d - 2) : 0;
@@ -558,7 +597,7 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                     // after issuing each pair -- the batches below would run one memory round trip per pair instead of GBATCH pairs in flight.
                     auto ld_slab = [&](int j, double& pa, double& pb) { pa = par[(long long)j * L]; pb = par[(long long)(j + S) * L]; };
 #if ES_WIDE_FUSE_GF
-                    if (d > 1 && d < 7 && (is_g || (ES_WIDE_FUSE_GF & 2))) {
+                    if (d > 1 && d < (DL < 7 ? DL : 7) && (is_g || (ES_WIDE_FUSE_GF & 2) || ((ES_WIDE_FUSE_GF & 4) && d + 1 == DL))) {
                         // Two levels in ONE pass: level d (the g of the bit just decided when it is the top of the step, else an f) and the f
                         // level below it.  The two level-d results that make an f operand pair -- elements i and i + S/2 -- are formed
                         // together, stored (their g child reads them later) and consumed from registers, so that level d+1 does not read
@@ -570,18 +609,20 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                             q[0] = par[(long long)j * L]; q[1] = par[(long long)(j + S) * L];
                             q[2] = par[(long long)(j + H) * L]; q[3] = par[(long long)(j + H + S) * L];
                         };
+                        // (the lower level's destination -- slab, or LDS when it is depth DL -- is chosen outside the element loops, like the loaders)
+                        auto fused_pass = [&](auto stB) {
                         auto pair_gf = [&](int j, const double (&q)[4], uint32_t u1, uint32_t u2) {
                             const double g1 = es_polar_g(q[0], q[1], u1), g2 = es_polar_g(q[2], q[3], u2);
                             dst[(long long)j * L] = g1;
                             dst[(long long)(j + H) * L] = g2;
-                            dstB[(long long)j * L] = es_polar_f(g1, g2, tab);
+                            stB(j, es_polar_f(g1, g2, tab));
                         };
                         auto pair_ff = [&](int j, const double (&q)[4]) {
                             const double f1 = es_polar_f(q[0], q[1], tab);
                             dst[(long long)j * L] = f1;
                             const double f2 = es_polar_f(q[2], q[3], tab);
                             dst[(long long)(j + H) * L] = f2;
-                            dstB[(long long)j * L] = es_polar_f(f1, f2, tab);
+                            stB(j, es_polar_f(f1, f2, tab));
                         };
                         const int blk = H < 32 ? H : 32;
                         for (int i0 = 0; i0 < H; i0 += blk) {
@@ -609,6 +650,11 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                                 }
                             }
                         }
+                        };
+                        bool to_lds = false;
+                        if constexpr (DL <= 7) to_lds = (d + 1 == DL);
+                        if (to_lds) { fused_pass([&](int j, double v) { W.low[j][p] = v; }); have_dl = true; }       // depth DL: rows 0 ..
+                        else fused_pass([&](int j, double v) { dstB[(long long)j * L] = v; });
                         pa_ = p8_set(pa_, d - 1, p);
                         ++d;                                                        // level d+1 is done too
                         pa_ = p8_set(pa_, d - 1, p);
@@ -687,59 +733,57 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                     }
                     pa_ = p8_set(pa_, d - 1, p);
                 }
-                // --- depth 8: slab -> LDS
-                if (top <= 8) {
-                    const double* par = A + (long long)8 * L + p8_get(pa_, 6);
-                    double x[8];
-                    #pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = par[(long long)u * L];
-                    if ((i >> 2) & 1) {
+                // --- depths DL..9 in LDS: level DL from the slab (unless a fused pass has just formed it), the others LDS -> LDS; S = 1024 >> d
+                // elements by slot.  (ES_WIDE_DEFER: the generic softplus as a cold path after the level instead of a branch per evaluation --
+                // bit 1 depth 8, bit 2 depth 9; levels of 8 or 16 elements always.)
+                auto low_level = [&](auto dc, auto from_slab) {
+                    constexpr int d = decltype(dc)::value;
+                    constexpr int S = N >> d;
+                    constexpr bool SLAB = decltype(from_slab)::value;
+                    constexpr bool DEFER = S > 4 || (d == 8 ? (ES_WIDE_DEFER & 2) : (ES_WIDE_DEFER & 4)) != 0;
+                    constexpr int rs = wide_low_row(DL, d - 1), rd = wide_low_row(DL, d);
+                    constexpr int C = S < 4 ? S : 4;                                  // f evaluations per chunk (registers are indexed statically: no private arrays)
+                    const int ps = p8_get(pa_, d - 2);                                // slot of my depth d-1 block
+                    const double* par = A + (long long)(2 * S) * L + ps;              // (SLAB: depth d-1 at elements [2S, 4S))
+                    auto src = [&](int e) -> double { if constexpr (SLAB) return par[(long long)e * L]; else return W.low[rs + e][ps]; };
+                    if ((i >> (NLEV - d)) & 1) {
+                        double x[2 * S];
                         #pragma unroll
-                        for (int j = 0; j < 4; ++j) W.low[j][p] = es_polar_g(x[j], x[j + 4], (b0 >> (4 + j)) & 1u);
-                    } else {
-#if ES_WIDE_DEFER & 2
+                        for (int u = 0; u < 2 * S; ++u) x[u] = src(u);
+                        #pragma unroll
+                        for (int j = 0; j < S; ++j) W.low[rd + j][p] = es_polar_g(x[j], x[j + S], (b0 >> (S + j)) & 1u);
+                    } else if constexpr (DEFER) {
                         int bad = 0;
-                        double y8[4];
-                        #pragma unroll
-                        for (int j = 0; j < 4; ++j) y8[j] = es_polar_f_fast(x[j], x[j + 4], tab, &bad);
-                        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ULL) {          // rare: the generic form
-                            #pragma unroll 1
-                            for (int j = 0; j < 4; ++j) y8[j] = es_polar_f(x[j], x[j + 4], tab);
+                        #pragma unroll 1
+                        for (int c = 0; c < S; c += C) {
+                            double x[2 * C];
+                            #pragma unroll
+                            for (int u = 0; u < C; ++u) { x[u] = src(c + u); x[C + u] = src(c + u + S); }
+                            #pragma unroll
+                            for (int u = 0; u < C; ++u) W.low[rd + c + u][p] = es_polar_f_fast(x[u], x[C + u], tab, &bad);
                         }
-                        #pragma unroll
-                        for (int j = 0; j < 4; ++j) W.low[j][p] = y8[j];
-#else
-                        #pragma unroll 2
-                        for (int j = 0; j < 4; ++j) W.low[j][p] = es_polar_f(x[j], x[j + 4], tab);
-#endif
-                    }
-                    pa_ = p8_set(pa_, 7, p);
-                }
-                // --- depth 9: LDS -> LDS
-                if (top <= 9) {
-                    const int ps = p8_get(pa_, 7);
-                    const double x0 = W.low[0][ps], x1 = W.low[1][ps], x2 = W.low[2][ps], x3 = W.low[3][ps];
-                    if ((i >> 1) & 1) {
-                        W.low[4][p] = es_polar_g(x0, x2, (b0 >> 2) & 1u);
-                        W.low[5][p] = es_polar_g(x1, x3, (b0 >> 3) & 1u);
+                        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ULL) {          // rare: the level again with the generic form
+                            #pragma unroll 1
+                            for (int j = 0; j < S; ++j) W.low[rd + j][p] = es_polar_f(src(j), src(j + S), tab);
+                        }
                     } else {
-#if ES_WIDE_DEFER & 4
-                        int bad = 0;
-                        double y0 = es_polar_f_fast(x0, x2, tab, &bad), y1 = es_polar_f_fast(x1, x3, tab, &bad);
-                        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ULL) { y0 = es_polar_f(x0, x2, tab); y1 = es_polar_f(x1, x3, tab); }
-                        W.low[4][p] = y0;
-                        W.low[5][p] = y1;
-#else
-                        W.low[4][p] = es_polar_f(x0, x2, tab);
-                        W.low[5][p] = es_polar_f(x1, x3, tab);
-#endif
+                        double x[2 * S];
+                        #pragma unroll
+                        for (int u = 0; u < 2 * S; ++u) x[u] = src(u);
+                        #pragma unroll 2
+                        for (int j = 0; j < S; ++j) W.low[rd + j][p] = es_polar_f(x[j], x[j + S], tab);
                     }
-                    pb_ = p8_set(pb_, 5, p);
-                }
+                    if constexpr (d <= 8) pa_ = p8_set(pa_, d - 1, p); else pb_ = p8_set(pb_, 5, p);
+                };
+                using std::integral_constant;
+                if (top <= DL && !have_dl) low_level(integral_constant<int, DL>{}, std::true_type{});
+                if constexpr (DL < 7) { if (top <= 7) low_level(integral_constant<int, 7>{}, std::false_type{}); }
+                if constexpr (DL < 8) { if (top <= 8) low_level(integral_constant<int, 8>{}, std::false_type{}); }
+                if (top <= 9) low_level(integral_constant<int, 9>{}, std::false_type{});
                 // --- depth 10: LDS -> register
                 {
                     const int ps = p8_get(pb_, 5);
-                    const double xa = W.low[4][ps], xb = W.low[5][ps];
+                    const double xa = W.low[lrow(9)][ps], xb = W.low[lrow(9) + 1][ps];
                     if (i & 1) lam = es_polar_g(xa, xb, (b0 >> 1) & 1u);
 #if ES_WIDE_DEFER & 8
                     else {
@@ -772,37 +816,63 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                 double k0 = live ? metric + ((pref != 0u) ? lp + al : lp) : __builtin_inf();
                 double k1 = live ? metric + ((pref != 1u) ? lp + al : lp) : __builtin_inf();
                 uint32_t i0 = live ? (uint32_t)(2 * pl) : 0xFFFFu, i1 = live ? (uint32_t)(2 * pl + 1) : 0xFFFFu;   // candidate index within the frame
-                // publish what follows a path through the sort
-                const int xb = (NB == 2) ? (info_idx & 1) : 0;
                 const bool wstart = (info_idx & 31) == 0;
-                W.xpa[xb][p] = pa_;
-                W.xpb[xb][p] = pb_ | ((uint64_t)(wstart ? (uint32_t)pl : anc) << 48);
-                W.xb0[xb][p] = b0;
-                W.xhist[xb][p] = wstart ? 0u : hist;
-                if (!(i & 1)) { W.xsp[xb][0][p] = sp_diff; W.xsp[xb][1][p] = sp_sum; }
-                int buf = 0;
-                wide_sort<L, LF>(k0, i0, k1, i1, p, pl, W, buf);
-                W.skey[buf][2 * p] = k0; W.skey[buf][2 * p + 1] = k1;
-                W.sidx[buf][2 * p] = (uint16_t)i0; W.sidx[buf][2 * p + 1] = (uint16_t)i1;
-                if constexpr (WAVE) wave_fence_lds(); else __syncthreads();
                 const int keep = nc < a.lsz ? nc : a.lsz;          // a.lsz <= LF: lists of any size run on the next power of two's kernel
                 const int myr = pl < keep ? pl : 0;                // dead paths mirror rank 0
-                const uint32_t myc = W.sidx[buf][2 * fp0 + myr];
-                metric = W.skey[buf][2 * fp0 + myr];
+                if constexpr (WAVE && ES_WIDE_GATHER_BPERM) {
+                    // One wave: the survivor of rank r takes sorted element r and then its parent's state straight from the registers of the
+                    // lanes that hold them (ds_bpermute: no LDS storage, no fence -- the lanes of a wave run in lock step).
+                    int buf = 0;
+                    wide_sort<L, LF>(k0, i0, k1, i1, p, pl, W, buf);
+                    auto fetch32 = [](int src, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v); };
+                    auto fetch64 = [&](int src, uint64_t v) { return ((uint64_t)fetch32(src, (uint32_t)(v >> 32)) << 32) | fetch32(src, (uint32_t)v); };
+                    const int holder = fp0 + (myr >> 1);           // sorted element e sits in lane e / 2 of the frame, half e % 2
+                    const uint64_t e0 = fetch64(holder, __builtin_bit_cast(uint64_t, k0)), e1 = fetch64(holder, __builtin_bit_cast(uint64_t, k1));
+                    const uint32_t ei = fetch32(holder, (i0 & 0xFFFFu) | (i1 << 16));
+                    metric = __builtin_bit_cast(double, (myr & 1) ? e1 : e0);
+                    const uint32_t myc = (myr & 1) ? (ei >> 16) : (ei & 0xFFFFu);
+                    const int parent = fp0 + ((int)(myc >> 1) & (LF - 1));
+                    bit = myc & 1u;
+                    const uint64_t t = fetch64(parent, pb_ | ((uint64_t)(wstart ? (uint32_t)pl : anc) << 48));
+                    pa_ = fetch64(parent, pa_);
+                    pb_ = t & 0xFFFFFFFFFFFFULL;
+                    anc = (uint32_t)(t >> 48);
+                    b0 = fetch32(parent, b0);
+                    hist = (fetch32(parent, wstart ? 0u : hist) << 1) | bit;
+                    if (!(i & 1)) {
+                        const uint64_t sd = fetch64(parent, __builtin_bit_cast(uint64_t, sp_diff)), ss = fetch64(parent, __builtin_bit_cast(uint64_t, sp_sum));
+                        lp_odd = __builtin_bit_cast(double, bit ? sd : ss);
+                    }
+                } else {
+                // publish what follows a path through the sort
+                const int xb = (NB == 2) ? (info_idx & 1) : 0;
+                W.pub.xpa[xb][p] = pa_;
+                W.pub.xpb[xb][p] = pb_ | ((uint64_t)(wstart ? (uint32_t)pl : anc) << 48);
+                W.pub.xb0[xb][p] = b0;
+                W.pub.xhist[xb][p] = wstart ? 0u : hist;
+                if (!(i & 1)) { W.pub.xsp[xb][0][p] = sp_diff; W.pub.xsp[xb][1][p] = sp_sum; }
+                int buf = 0;
+                wide_sort<L, LF>(k0, i0, k1, i1, p, pl, W, buf);
+                W.pub.skey[buf][2 * p] = k0; W.pub.skey[buf][2 * p + 1] = k1;
+                W.pub.sidx[buf][2 * p] = (uint16_t)i0; W.pub.sidx[buf][2 * p + 1] = (uint16_t)i1;
+                if constexpr (WAVE) wave_fence_lds(); else __syncthreads();
+                const uint32_t myc = W.pub.sidx[buf][2 * fp0 + myr];
+                metric = W.pub.skey[buf][2 * fp0 + myr];
                 const int parent = fp0 + ((int)(myc >> 1) & (LF - 1));
                 bit = myc & 1u;
-                pa_ = W.xpa[xb][parent];
-                const uint64_t t = W.xpb[xb][parent];
+                pa_ = W.pub.xpa[xb][parent];
+                const uint64_t t = W.pub.xpb[xb][parent];
                 pb_ = t & 0xFFFFFFFFFFFFULL;
                 anc = (uint32_t)(t >> 48);
-                b0 = W.xb0[xb][parent];
-                hist = (W.xhist[xb][parent] << 1) | bit;
-                if (!(i & 1)) lp_odd = W.xsp[xb][bit ? 0 : 1][parent];
+                b0 = W.pub.xb0[xb][parent];
+                hist = (W.pub.xhist[xb][parent] << 1) | bit;
+                if (!(i & 1)) lp_odd = W.pub.xsp[xb][bit ? 0 : 1][parent];
+                }
                 if ((info_idx & 31) == 31) { TBW[(info_idx >> 5) * L + p] = hist; TBA[(info_idx >> 5) * L + p] = (uint16_t)anc; }
                 cnt = keep;
                 ++info_idx;
                 if constexpr (!WAVE) dirty = false;                // every wave passed the sort's barriers after its reads
-                else wave_fence_lds();                             // (one wave: the published rows are rewritten two sorts later, in order)
+                else if constexpr (!ES_WIDE_GATHER_BPERM) wave_fence_lds();   // (one wave: the published rows are rewritten two sorts later, in order)
             }
 
             // --- partial sums: fold upward while the node is a right child (fastpolar.py:156-183); each lane its own path
@@ -844,11 +914,11 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
 
         // ---------------- final ordering (fastpolar.py:335), trace-back, CRC -- per frame
         group_sync();
-        W.skey[0][2 * p] = metric;                                  // (a lane's own sort cells: waves that are groups of their own run out of step)
+        W.low[0][p] = metric;                                       // (the list loop is over: the LLR rows are free; a lane's own cell -- waves that are groups of their own run out of step)
         group_sync();
         int rank = 0;
         for (int k = 0; k < cnt; ++k) {
-            const double mk = W.skey[0][2 * (fp0 + k)];
+            const double mk = W.low[0][fp0 + k];
             rank += ((mk < metric) || (mk == metric && k < pl)) ? 1 : 0;
         }
         if constexpr (GK) {
@@ -924,7 +994,9 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
     const size_t lds = sizeof(WideLds<L, (LF > 64 ? 2 : 1)>);
     static_assert((sizeof(WideLds<256, 2>) + 1279) / 1280 * 1280 * 3 <= 160 * 1024, "three workgroups per CU at L = 256 (LDS is handed out in 1 280-byte granules)");
     static_assert((sizeof(WideLds<128, 2>) + 1279) / 1280 * 1280 * 6 <= 160 * 1024, "six two-wave workgroups per CU at L = 128");
-    static_assert((sizeof(WideLds<64, 1>) + 1279) / 1280 * 1280 * 12 <= 160 * 1024, "twelve one-wave workgroups per CU");
+#if ES_WIDE_GATHER_BPERM && ES_WIDE_LDS_DEPTH >= 7
+    static_assert((sizeof(WideLds<64, 1>) + 1279) / 1280 * 1280 * 4 * ES_WIDE_WPS <= 160 * 1024, "4 x ES_WIDE_WPS one-wave workgroups per CU");
+#endif
     static_assert((LF & (LF - 1)) == 0, "power of two");
     constexpr unsigned attr_bit = (unsigned)LF << (GK ? 9 : 0);        // one instantiation per list capacity (and per kind of code)
     if (!(ctx->wide_attr_mask & attr_bit)) {                           // per context (= per device): the attribute belongs to the device's copy of the kernel

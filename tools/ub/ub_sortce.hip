@@ -14,7 +14,7 @@
                      "v_cndmask_b32_dpp %2, %2, %2, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                             \
                      "v_cndmask_b32_dpp %0, %0, %0, vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"                             \
                      "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL " row_mask:0xf bank_mask:0xf"                                 \
-                     : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "s"(tmask) : "vcc");                                        \
+                     : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "s"(tmask) : "vcc", "scc");                                 \
     } while (0)
 __device__ __forceinline__ void ce_pair(uint32_t& lo, uint32_t& hi, uint32_t& ix, uint32_t olo, uint32_t ohi, uint32_t oix, unsigned long long tmask)
 {
@@ -26,7 +26,7 @@ __device__ __forceinline__ void ce_pair(uint32_t& lo, uint32_t& hi, uint32_t& ix
                  "v_cndmask_b32 %2, %6, %2, vcc\n\t"
                  "v_cndmask_b32 %0, %4, %0, vcc\n\t"
                  "v_cndmask_b32 %1, %5, %1, vcc"
-                 : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "v"(olo), "v"(ohi), "v"(oix), "s"(tmask) : "vcc");
+                 : "+v"(lo), "+v"(hi), "+v"(ix), "=&v"(t_) : "v"(olo), "v"(ohi), "v"(oix), "s"(tmask) : "vcc", "scc");
 }
 __device__ __forceinline__ void ce_inlane(uint32_t& lo0, uint32_t& hi0, uint32_t& ix0, uint32_t& lo1, uint32_t& hi1, uint32_t& ix1, unsigned long long amask)
 {
@@ -42,7 +42,7 @@ __device__ __forceinline__ void ce_inlane(uint32_t& lo0, uint32_t& hi0, uint32_t
                  "v_cndmask_b32 %8, %8, %5, vcc\n\t"
                  "v_cndmask_b32 %9, %9, %6, vcc"
                  : "=&v"(nlo0), "=&v"(nhi0), "=&v"(nix0), "=&v"(t_), "+v"(lo0), "+v"(hi0), "+v"(ix0), "+v"(lo1), "+v"(hi1), "+v"(ix1)
-                 : "s"(amask) : "vcc");
+                 : "s"(amask) : "vcc", "scc");
     lo0 = nlo0; hi0 = nhi0; ix0 = nix0;
 }
 __device__ bool before(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) { return ka < kb || (ka == kb && ia < ib); }
