@@ -13,6 +13,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libechoseal_hip.so")
+if os.environ.get("ES_LIB_VARIANT"):           # development: an A/B build made by tools/build_variant.sh (same ABI check, same loud failure when missing)
+    LIB_PATH = os.path.join(_HERE, f"libechoseal_hip_{os.environ['ES_LIB_VARIANT']}.so")
 
 ES_ABI_VERSION = 2          # include/echoseal_hip.h; load() refuses a library built from another one
 ES_FRAME_LEN = 1215

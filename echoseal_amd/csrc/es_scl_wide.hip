@@ -60,6 +60,9 @@
 #ifndef ES_WIDE_FDIST
 #define ES_WIDE_FDIST 2                           /* f loops: operand pairs requested this many f evaluations ahead (1: rotation by copy; 2: unrolled by three) */
 #endif
+#ifndef ES_WIDE_L1R
+#define ES_WIDE_L1R 1                             /* the g half of tree depth 1 is never stored: its elements are llr[e + 512] +- llr[e] by one partial-sum bit, formed on the fly by the two passes that consume them (bits 512 and 768) */
+#endif
 #ifndef ES_WIDE_LDS_DEPTH
 #define ES_WIDE_LDS_DEPTH 7                       /* one-wave blocks: first LLR-tree depth kept in LDS (7: 8 + 4 + 2 rows of doubles by slot; 8: round 3's layout; 6 needs two waves per SIMD) */
 #endif
@@ -122,9 +125,8 @@ struct WideLds {
     uint64_t exp_tab[ES_EXP_TAB_WORDS];
     double   low[NLOW][L];              // depths DL..9, by slot (also: the hard decision's 184 bytes and the final ordering's metrics, outside the list loop)
     uint32_t betaM[3][L];               // partial-sum blocks of 32 (row 0) and 64 bits (1, 2), by slot (wider ones, touched a few times per frame: slab)
-    int      fr[64];                    // frames drawn from the cursor (up to 64 per one-wave block)
     int      flag;
-    WidePub<L, NB> pub;
+    WidePub<L, NB> pub;                 // (the frames drawn from the cursor, up to 64 ints per one-wave block, borrow row 1 of `low` before the list loop starts)
 };
 
 __device__ __forceinline__ uint64_t p8_set(uint64_t w, int k, int v) { const int sh = 8 * k; return (w & ~(255ULL << sh)) | ((uint64_t)(uint32_t)v << sh); }
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
     auto lrow = [](int d) constexpr { return wide_low_row(WLds::DL, d); };                   // its first row in W.low
     uint32_t* const hd_words = reinterpret_cast<uint32_t*>(&W.low[0][0]);                   // 32 words ...
     uint8_t* const hd_bytes = reinterpret_cast<uint8_t*>(&W.low[0][16]);                    // ... and up to 128 bytes of the hard decision (first wave; the rows are idle outside the list loop)
+    int* const drawn = reinterpret_cast<int*>(&W.low[1][0]);                                 // frames drawn from the cursor (<= 64 ints), read back before the list loop writes the rows
     const long long n_groups = a.cursor ? (long long)gridDim.x : (a.B + FRG - 1) / FRG;      // (cursor: one draw per block)
     for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {      // one group of FRG frames per block (grid = groups)
         long long f; bool f_valid;
@@ -480,19 +483,19 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                         for (int k = lane; k < a.lsz * NIB; k += 64) a.cand_info[(long long)ff * a.lsz * NIB + k] = 0;
                         #pragma unroll 1
                         for (int k = lane; k < a.lsz; k += 64) { a.cand_metric[(long long)ff * a.lsz + k] = 0.0; a.cand_ok[(long long)ff * a.lsz + k] = 0; }
-                    } else { if (lane == 0) W.fr[n] = ff; ++n; }
+                    } else { if (lane == 0) drawn[n] = ff; ++n; }
                 }
                 wave_fence_lds();
                 if (n == 0) break;
                 f_valid = (lane / LF) < n;
-                f = W.fr[f_valid ? lane / LF : 0];             // a missing frame mirrors the first one (never stored)
+                f = drawn[f_valid ? lane / LF : 0];             // a missing frame mirrors the first one (never stored)
                 active_mask = (n >= 64) ? ~0ULL : ((1ULL << n) - 1ULL);
             } else {
                 int ff;
                 for (;;) {
-                    if (p == 0) W.fr[0] = atomicAdd(a.cursor, 1);
+                    if (p == 0) drawn[0] = atomicAdd(a.cursor, 1);
                     __syncthreads();
-                    ff = W.fr[0];
+                    ff = drawn[0];
                     if (ff >= a.B) break;
                     if (wv == 0) {
                         const int ok = hard_decision_wave<GK>(a, ff, lane, hd_words, hd_bytes, a.data_pos);
@@ -586,7 +589,69 @@ __global__ __launch_bounds__(L, ES_WIDE_WPS) void es_scl_wide_kernel(WideArgs a)
                 if (top <= 9 && dirty) { group_sync(); dirty = false; }         // this step writes slots
                 // --- depths top..DL-1: slab to slab, the lane walks the node
                 bool have_dl = false;                                               // depth DL already formed (in LDS) by a fused pass of this step
-                for (int d = top; d < DL; ++d) {
+                int d_first = top;
+#if ES_WIDE_L1R
+                // Depth 1 of the SECOND half of the code word (bits 512..) is g(llr[e], llr[e + 512], u1[e]) = llr[e + 512] +- llr[e]: one bit of the
+                // 512-bit partial-sum block picks one of two values that the frame's channel LLRs already hold.  It is never stored (512 doubles written
+                // and twice read per path otherwise: 8.5 % of the slab traffic, and a 512-element load-add-store loop): the two passes that consume it --
+                // the f level of depth 2 at bit 512, the g level of depth 2 (fused with the f level of depth 3) at bit 768 -- form its elements on the
+                // fly from the channel LLRs (shared by the frame's paths: the lanes of a frame read the same addresses).
+                // (float32 channel LLRs -- what es_llr_batch produces; a float64 launch keeps depth 1 in the slab.  The operands come from the L1 / L2,
+                // not from the slab: one operand set ahead, rotated by copy, is enough.)
+                if ((i == 512 || i == 768) && !a.is_f64) {
+                    const int bs1 = p8_get(pb_, 0);                                 // slot of my 512-bit partial-sum block
+                    double* const dst2 = A + (long long)256 * L + p;                // depth 2 at elements [256, 512)
+                    auto g1 = [&](float lo, float hi, uint32_t u) { return es_polar_g((double)lo, (double)hi, u); };      // depth-1 element from llr[e], llr[e + 512]
+                    if (i == 512) {
+                        auto ld = [&](int j, float (&q)[4]) { q[0] = llr32[j]; q[1] = llr32[j + 512]; q[2] = llr32[j + 256]; q[3] = llr32[j + 768]; };
+                        float q[4], qn[4];
+                        ld(0, q);
+                        #pragma unroll 1
+                        for (int j0 = 0; j0 < 256; j0 += 32) {
+                            const uint32_t wa = beta_ld((512 + j0) >> 5, bs1), wb = beta_ld((512 + j0 + 256) >> 5, bs1);
+                            #pragma unroll 1
+                            for (int u = 0; u < 32; ++u) {
+                                const int j = j0 + u;
+                                ld(j < 255 ? j + 1 : 255, qn);
+                                dst2[(long long)j * L] = es_polar_f(g1(q[0], q[1], (wa >> u) & 1u), g1(q[2], q[3], (wb >> u) & 1u), tab);
+                                #pragma unroll
+                                for (int k = 0; k < 4; ++k) q[k] = qn[k];
+                            }
+                        }
+                    } else {
+                        const int bs2 = p8_get(pb_, 1);                             // slot of my 256-bit block
+                        double* const dst3 = A + (long long)128 * L + p;            // depth 3 at elements [128, 256)
+                        auto ld = [&](int j, float (&q)[8]) {
+                            q[0] = llr32[j]; q[1] = llr32[j + 512]; q[2] = llr32[j + 256]; q[3] = llr32[j + 768];
+                            q[4] = llr32[j + 128]; q[5] = llr32[j + 640]; q[6] = llr32[j + 384]; q[7] = llr32[j + 896];
+                        };
+                        float q[8], qn[8];
+                        ld(0, q);
+                        #pragma unroll 1
+                        for (int j0 = 0; j0 < 128; j0 += 32) {
+                            const uint32_t w1a = beta_ld((512 + j0) >> 5, bs1), w1b = beta_ld((512 + j0 + 256) >> 5, bs1);
+                            const uint32_t w1c = beta_ld((512 + j0 + 128) >> 5, bs1), w1d = beta_ld((512 + j0 + 384) >> 5, bs1);
+                            const uint32_t w2a = beta_ld((256 + j0) >> 5, bs2), w2b = beta_ld((256 + j0 + 128) >> 5, bs2);
+                            #pragma unroll 1
+                            for (int u = 0; u < 32; ++u) {
+                                const int j = j0 + u;
+                                ld(j < 127 ? j + 1 : 127, qn);
+                                const double x = es_polar_g(g1(q[0], q[1], (w1a >> u) & 1u), g1(q[2], q[3], (w1b >> u) & 1u), (w2a >> u) & 1u);   // depth-2 element j
+                                const double y = es_polar_g(g1(q[4], q[5], (w1c >> u) & 1u), g1(q[6], q[7], (w1d >> u) & 1u), (w2b >> u) & 1u);   // ... and j + 128
+                                dst2[(long long)j * L] = x;
+                                dst2[(long long)(j + 128) * L] = y;
+                                dst3[(long long)j * L] = es_polar_f(x, y, tab);
+                                #pragma unroll
+                                for (int k = 0; k < 8; ++k) q[k] = qn[k];
+                            }
+                        }
+                    }
+                    pa_ = p8_set(pa_, 1, p);
+                    d_first = 3;
+                    if (i == 768) { pa_ = p8_set(pa_, 2, p); d_first = 4; }
+                }
+#endif
+                for (int d = d_first; d < DL; ++d) {
                     const int S = N >> d;
                     const bool is_g = (i >> (NLEV - d)) & 1;
                     const int ps = (d > 1) ? p8_get(pa_, d - 2) : 0;
