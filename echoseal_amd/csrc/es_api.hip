@@ -469,11 +469,6 @@ int es_set_option(es_ctx* ctx, const char* name, int value)
         ctx->scl_multi = value;
         return ES_OK;
     }
-    if (std::strcmp(name, "xcorr_mfma") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, ES_EINVAL, "es_set_option: xcorr_mfma takes 0 or 1");
-        ctx->xcorr_mfma = value;
-        return ES_OK;
-    }
     if (std::strcmp(name, "scl_prio") == 0) {
         if (value < 0 || value > 3) return fail(ctx, ES_EINVAL, "es_set_option: scl_prio takes 0..3");
         ctx->scl_prio = value;

@@ -57,7 +57,6 @@ struct es_ctx {
     int scl_lanes = 0;                /* lanes per path of the multi-frame list decoder: 4 (16 paths per wave), 2 (32 paths per wave), 0 = by batch size */
     int scl_prio = 0;                 /* wave priority of the lane-per-path list decoder's launches (0..3) */
     int scl_multi = -1;               /* several frames per wave for list sizes <= 8: -1 auto (large batches), 0 never, 1 always */
-    int xcorr_mfma = 0;               /* es_xcorr32_batch on 2 048-sample windows (large batches): numerators on the matrix pipe (1) or packed vector FMAs (0) */
 };
 
 #define ES_HIP_CHECK(ctx, expr)                                                         \

@@ -222,197 +222,6 @@ void es_xcorr32_kernel(const float* __restrict__ y, long long B,
     }
 }
 
-// ------------------------------------------------------------------------------------ xcorr32 on the matrix pipe
-// The 63-tap correlation is a Toeplitz contraction: with lag = 256 t + 16 n + i (tile t, i, n in 0..15) and m = i + k,
-//     num[256 t + 16 n + i] = sum_{m = 0}^{79} tpl[m - i] * y[256 t + 16 n + m]          (tpl[j] = 0 outside 0..62)
-// is D[i][n] = sum_m A[i][m] B[m][n] with A the template's Toeplitz matrix (16 x 80, the same for every tile of a band) and
-// B[m][n] = y[256 t + 16 n + m]: twenty v_mfma_f32_16x16x4_f32 per 256 lags.  On gfx950 that instruction IS an ascending fmaf chain
-// over k with one rounding per product (no wider accumulator), and a product with a zero tap leaves the accumulator as it is -- so
-// every numerator is the 63-term float32 FMA chain over ascending taps, inside the error bound stated at the top of this file
-// (63 x 2^-24 of sum|y||tpl|) exactly as the packed-FMA kernel's two half chains are.  What moves is WHERE the 1 071 FMAs per lane
-// run: the float32 matrix rate equals the packed vector rate (64 FLOP / clock / SIMD), but the matrix pipe is otherwise idle and the
-// vector unit was the kernel's co-limit next to HBM (3 400 issue cycles per 1 088 lags against 2 560 matrix cycles per 1 024 lags
-// beside ~1 300 vector cycles of energies, normalisation and staging that other waves issue meanwhile).
-// A wave owns (record, segment of 1 024 lags = four tiles).  Samples sit in LDS at x + (x >> 4) (one pad word per 16: the B operand's
-// lanes read with a stride of 16 samples); energies are formed as in the packed kernel by the lane that owns 16 consecutive lags --
-// en = (head + core) + tail, all terms >= 0 -- and handed to the accumulator layout (lane = (q, c): lags 256 t + 16 c + 4 q + 0..3, four
-// consecutive floats per lane: one 16-byte store, a wave's store instruction covers 1 KB contiguous) through LDS as the factor 1/sqrt(en).
-constexpr int XM_WAVES = 4;
-#ifndef XM_MIN_WAVES
-#define XM_MIN_WAVES 4                               // waves per SIMD the register allocation must allow (= resident blocks per CU)
-#endif
-#define XM_GRID_PER_CU XM_MIN_WAVES                  // the grid is capped at the resident blocks; grid-stride beyond
-constexpr int XM_SEG = 1024;                        // lags per item
-constexpr int XM_NS = XM_SEG + 64;                  // samples staged per item: lags + 62 taps, + 2 (80 = 20 steps of 4 in m)
-constexpr int XM_ROW = 20;                          // LDS words per 16 samples: x sits at x + 4 (x >> 4) (rows stay 16-byte aligned)
-constexpr int XM_SMP = XM_NS / 16 * XM_ROW;         // padded sample row
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-struct __attribute__((packed, aligned(4))) f32x4_store { float v[4]; };     // 16 bytes at the 8-byte alignment a correlation row has
-
-template <int TC>
-__global__ __launch_bounds__(64 * XM_WAVES, XM_MIN_WAVES)
-void es_xcorr32_mfma_kernel(const float* __restrict__ y, long long B, int T_arg, const uint8_t* __restrict__ band,
-                            const es_band_tables* __restrict__ tabs, float* __restrict__ corr)
-{
-    const int T = TC ? TC : T_arg;
-    __builtin_amdgcn_s_setprio(3);
-    __shared__ __attribute__((aligned(16))) float s_smp[XM_WAVES][XM_SMP];
-    __shared__ float s_tz[ES_NBANDS][96];           // tz[b][15 + j] = tpl32[b][j], zeros around: the Toeplitz operand reads tz[15 + m - i]
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int i = threadIdx.x; i < ES_NBANDS * 96; i += 64 * XM_WAVES) {
-        const int b = i / 96, j = i % 96 - 15;
-        s_tz[b][i % 96] = (j >= 0 && j < ES_PRE_L) ? tabs->tpl32[b][j] : 0.0f;
-    }
-    __syncthreads();
-    float* const s = s_smp[wv];
-    const int n_lags = T - (ES_PRE_L - 1);
-    const int nseg = (n_lags + XM_SEG - 1) / XM_SEG;
-    const long long n_items = B * nseg;
-    const unsigned stride = gridDim.x * XM_WAVES;
-    auto rec_of = [&](unsigned it) { return nseg == 1 ? it : (nseg == 2 ? it >> 1 : it / (unsigned)nseg); };
-    // 16-byte loads: lane takes samples 4 lane + 256 u + 0..3 (u = 0..3: inside every segment of a record whose length is a multiple of
-    // 1 024; u = 4: the 64 samples past the segment's lags, sixteen lanes, where the record goes on)
-    static_assert(TC > 0 && TC % XM_SEG == 0, "the matrix-pipe screen is instantiated for records of whole 1 024-sample segments");
-    f32x4 stage[5];
-    int bi_next = 0;
-    auto prefetch = [&](unsigned it) {
-        const long long r = rec_of(it);
-        const int l0 = (int)(it - (unsigned)r * (unsigned)nseg) * XM_SEG;
-        const f32x4* src = reinterpret_cast<const f32x4*>(y + r * T + l0) + lane;
-        #pragma unroll
-        for (int u = 0; u < 4; ++u) stage[u] = src[64 * u];
-        // past the record's end: ones, not zeros -- no stored lag's window reaches them and their taps are zero, but the lags that are
-        // computed and dropped then have ordinary energies and need no masking when the wave chooses the form of its normalisation
-        stage[4] = (lane < 16 && l0 + XM_SEG < T) ? src[256] : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
-        bi_next = (int)band[r];
-    };
-    unsigned item = blockIdx.x * XM_WAVES + wv;
-    if (item >= (unsigned)n_items) return;
-    const int c = lane & 15, q = lane >> 4;          // matrix operand / accumulator coordinates of the lane
-    // The k index of the matrix instruction is free to enumerate m in any order as long as both operands agree: lane group q takes
-    // m = 20 q + kk (kk = 0..19), twenty CONSECUTIVE samples per lane -- five 16-byte LDS reads (256 B / clock) instead of twenty 4-byte
-    // ones (128 B / clock).  Sample 256 t + 16 c + 20 q + 4 i sits at 320 t + 20 c + 24 q + 4 i + 4 [i >= 4 - q] (the pad words of the
-    // rows it crosses).
-    const float* yb[5];
-    #pragma unroll
-    for (int i = 0; i < 5; ++i) yb[i] = s + XM_ROW * c + 24 * q + 4 * i + (i >= 4 - q ? 4 : 0);
-    prefetch(item);
-    auto body = [&](unsigned item) __attribute__((always_inline)) {
-        const long long rec = rec_of(item);
-        const int lag0 = (int)(item - (unsigned)rec * (unsigned)nseg) * XM_SEG;
-        const int nl = n_lags - lag0;                                             // valid lags of this segment (may exceed 1 024)
-        const int bi = __builtin_amdgcn_readfirstlane(bi_next);
-        #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(s + 4 * lane + 4 * (lane >> 2) + 320 * u) = stage[u];   // x = 4 lane + 256 u -> x + 4 (x >> 4)
-        if (lane < 16) *reinterpret_cast<f32x4*>(s + 4 * lane + 4 * (lane >> 2) + 1280) = stage[4];
-        if (item + stride < (unsigned)n_items) prefetch(item + stride);
-        const float* tzl = s_tz[bi] + 15 + 20 * q - c;                            // A[i = c][m = 20 q + kk] = tpl[m - i] = tzl[kk]
-        wave_fence_lds();
-
-        // numerators
-        f32x4 acc[4];
-        #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            f32x4 yv[4];
-            #pragma unroll
-            for (int t = 0; t < 4; ++t) yv[t] = *reinterpret_cast<const f32x4*>(yb[i] + 16 * XM_ROW * t);
-            #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float ta = tzl[4 * i + e];
-#if defined(XM_ABLATE) && (XM_ABLATE & 1)
-                #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t][e] += ta * yv[t][e];
-#else
-                #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta, yv[t][e], acc[t], 0, 0, 0);
-#endif
-            }
-        }
-        // energies of the 16 lags 16 lane + r: samples x = 16 lane + j sit at 20 lane + j + 4 (j >> 4), read four at a time
-        const float* w = s + XM_ROW * lane;
-#if defined(XM_ABLATE) && (XM_ABLATE & 2)
-        #define XM_LD4(i) (f32x4{1.0f, 2.0f, 3.0f, (float)(i)})
-#else
-        #define XM_LD4(i) (*reinterpret_cast<const f32x4*>(w + 4 * (i) + 4 * ((i) >> 2)))
-#endif
-        float en[16];
-        {
-            const f32x4 h0 = XM_LD4(0), h1 = XM_LD4(1), h2 = XM_LD4(2), h3 = XM_LD4(3);
-            const float hv[16] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3], h2[0], h2[1], h2[2], h2[3], h3[0], h3[1], h3[2], h3[3]};
-            en[15] = 0.0f;
-            #pragma unroll
-            for (int r = 14; r >= 0; --r) en[r] = __builtin_fmaf(hv[r], hv[r], en[r + 1]);
-            f32x2 core2 = f32x2{hv[15] * hv[15], 0.0f};
-            #pragma unroll
-            for (int i = 4; i <= 14; ++i) {
-                const f32x4 v = XM_LD4(i);
-                core2 = __builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{v[0], v[1]}, core2);
-                core2 = __builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{v[2], v[3]}, core2);
-            }
-            const f32x4 m = XM_LD4(15);                                           // samples 60 .. 63
-            core2 = __builtin_elementwise_fma(f32x2{m[0], m[1]}, f32x2{m[0], m[1]}, core2);
-            const float core = __builtin_fmaf(m[2], m[2], core2.x + core2.y);     // samples 15 .. 62: in the window of each of the 16 lags
-            #pragma unroll
-            for (int r = 0; r < 16; ++r) en[r] = en[r] + core;
-            const f32x4 t0 = XM_LD4(16), t1 = XM_LD4(17), t2 = XM_LD4(18), t3 = XM_LD4(19);
-            const float tv[15] = {m[3], t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3], t3[0], t3[1]};
-            float tail_run = 0.0f;
-            #pragma unroll
-            for (int r = 1; r < 16; ++r) { tail_run = __builtin_fmaf(tv[r - 1], tv[r - 1], tail_run); en[r] = en[r] + tail_run; }
-        }
-        #undef XM_LD4
-        float emin = en[0], emax = en[0];
-        #pragma unroll
-        for (int r = 1; r < 16; ++r) { emin = __builtin_fminf(emin, en[r]); emax = __builtin_fmaxf(emax, en[r]); }
-        // the factor a numerator is multiplied with: the packed kernel's two forms (see there)
-        float fac[16];
-        if (__builtin_amdgcn_ballot_w64(!(emin >= 1.0e-12f && emax < 3.0e38f)) == 0) {
-            #pragma unroll
-            for (int r = 0; r < 16; ++r) fac[r] = __builtin_amdgcn_rsqf(en[r]);
-        } else {
-            #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                fac[r] = (en[r] < 3.0e38f) ? __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(en[r]) + 1e-12f) : __builtin_nanf("");
-        }
-
-        wave_fence_lds();
-        // the samples are dead: the factors go through their LDS.  Owner lane a, lag r -> 20 a + r; accumulator (q, c) of tile t holds
-        // lags 256 t + 16 c + 4 q + 0..3, whose factors sit at 320 t + 20 c + 4 q
-        #pragma unroll
-        for (int r = 0; r < 16; r += 4) *reinterpret_cast<f32x4*>(s + XM_ROW * lane + r) = f32x4{fac[r], fac[r + 1], fac[r + 2], fac[r + 3]};
-        wave_fence_lds();
-        // ... where the products go back to, so that lane l can fetch lags 256 t + 4 l + 0..3 for a store instruction that covers 1 KB in
-        // lane order (stored straight from the accumulator layout, a quarter wave wrote sixteen 16-byte pieces 64 bytes apart)
-        #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4* fp = reinterpret_cast<f32x4*>(s + 16 * XM_ROW * t + XM_ROW * c + 4 * q);
-            const f32x4 f = *fp;
-            *fp = f32x4{acc[t][0] * f[0], acc[t][1] * f[1], acc[t][2] * f[2], acc[t][3] * f[3]};
-        }
-        wave_fence_lds();
-        float* cr = corr + rec * n_lags + lag0;
-        #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 r4 = *reinterpret_cast<const f32x4*>(s + 16 * XM_ROW * t + 4 * lane + 4 * (lane >> 2));
-            const int l = 256 * t + 4 * lane;
-            f32x4_store o;
-            #pragma unroll
-            for (int v = 0; v < 4; ++v) o.v[v] = r4[v];
-            if (l + 3 < nl) *reinterpret_cast<f32x4_store*>(cr + l) = o;
-            else {
-                #pragma unroll
-                for (int v = 0; v < 4; ++v) if (l + v < nl) cr[l + v] = o.v[v];
-            }
-        }
-        wave_fence_lds();
-    };
-    body(item);
-    for (item += stride; item < (unsigned)n_items; item += stride) body(item);
-}
-
 // ------------------------------------------------------------------------------------ exact value
 // corr64 of one lag, bit-identical to es_xcorr_kernel / eso_ncc: FMA chain over ascending taps;
 // energy = (head + core) + tail over the 19-lag chunk the lag belongs to.
@@ -1093,16 +902,6 @@ int es_launch_xcorr32(es_ctx* ctx, const float* y32, int64_t B, int T, const uin
     // fewer single-segment items than two waves per SIMD: split records four ways
     const bool small = B * ((n_lags + XC_SEG - 1) / XC_SEG) < (long long)ctx->num_cu * 8;
     const bool win2k = !small && T == XC_T_WINDOW;              // config-3 windows: two waves per window, 17 lags per lane, compile-time bounds
-    if (win2k && ctx->xcorr_mfma != 0) {                         // numerators on the matrix pipe (es_xcorr32_mfma_kernel)
-        const long long items = B * ((n_lags + XM_SEG - 1) / XM_SEG);
-        long long mblocks = (items + XM_WAVES - 1) / XM_WAVES;
-        const long long mcap = (long long)ctx->num_cu * XM_GRID_PER_CU;
-        if (mblocks > mcap) mblocks = mcap;
-        hipLaunchKernelGGL((es_xcorr32_mfma_kernel<XC_T_WINDOW>), dim3((unsigned)mblocks), dim3(64 * XM_WAVES), 0, st, y32,
-                           (long long)B, T, band, ctx->d_tables, corr32);
-        ES_HIP_CHECK(ctx, hipGetLastError());
-        return ES_OK;
-    }
     const int seg = small ? 64 * XC_R_SMALL : (win2k ? 64 * XC_R_WINDOW : XC_SEG);
     const long long nseg = (n_lags + seg - 1) / seg;
     long long blocks = (B * nseg + XC_WAVES - 1) / XC_WAVES;

@@ -249,10 +249,7 @@ int es_softplus_batch(es_ctx* ctx, const double* t_dev, int64_t n, double* out_d
  * it from the start) without forcing anything: an allocation, so it belongs next to es_create / es_reserve, never between
  * enqueue calls that must not synchronise.  "scl_lanes" = 1 allocates it too.  "scl_prio" (0..3, default 0): wave priority
  * of the one-lane-per-path launches that follow -- a pipeline gives the later launch of a burst 1 so that it does not finish as
- * much later as it started (the short front-end kernels issue at 2 and 3).  "xcorr_mfma" (0 default, 1): es_xcorr32_batch on large
- * batches of 2 048-sample windows forms its numerators on the matrix pipe (Toeplitz form, v_mfma_f32_16x16x4_f32: the same ascending
- * float32 FMA chain per lag, the same error bound) instead of packed vector FMAs; screens differ in the last ulps, every decision
- * downstream (es_pick_exact_batch) is identical.                                                                          */
+ * much later as it started (the short front-end kernels issue at 2 and 3).                                                                          */
 int es_set_option(es_ctx* ctx, const char* name, int value);
 
 /* ---- the step after the list decoder ------------------------------------------------

@@ -551,48 +551,6 @@ def test_sync_fast_equals_float64_path(engine, oracle):
         assert th == float(fast.thr[i]) and bool(int(fast.npeaks[i]) >> 30) == fb
         assert list(fast.peaks[i, :kk].cpu().numpy()) == list(peaks[:kk])
 
-@pytest.mark.gpu
-def test_xcorr32_matrix_pipe_option(engine):
-    """es_xcorr32_batch on 2 048-sample windows with the numerators on the matrix pipe (option xcorr_mfma = 1: the Toeplitz form on
-    v_mfma_f32_16x16x4_f32, an ascending float32 FMA chain per lag) against the packed-vector kernel (0, the default): both screens
-    within the proven bound of the float64 correlation, and es_pick_exact_batch settles every record identically from either --
-    clean, noisy, adversarial and near-threshold records, over digital silence (degenerate: float64 redo) and over a noise floor."""
-    rng = np.random.default_rng(2027)
-    frames, band, pn = _workload(192)
-    noisy = (frames[:96] + rng.normal(0, 0.15, (96, 1215))).astype(np.float32)
-    adv = _adversarial_records(rng, 32, 1215)
-    near = np.stack([(frames[i] * a + rng.normal(0, 0.05, 1215)).astype(np.float32)
-                     for i, a in zip(range(64), np.linspace(0.28, 0.42, 64))])
-    x = np.concatenate([frames, noisy, adv, near])
-    bnd = np.concatenate([band, band[:96], rng.integers(0, 4, 32).astype(np.uint8), band[:64]])
-    x, bnd = np.tile(x, (3, 1)), np.tile(bnd, 3)                       # 1 152 records: the large-batch launch (two waves per window)
-    lead = rng.integers(0, 2048 - 1215, x.shape[0])
-    win = np.zeros((x.shape[0], 2048), np.float32)
-    for i, l0 in enumerate(lead):
-        win[i, l0:l0 + 1215] = x[i]
-    floor = rng.normal(0, 1e-3, win.shape).astype(np.float32)
-    try:
-        for name, xx in (("zero padded", win), ("noise floor", win + floor)):
-            f, b = _dev(engine, xx, bnd)
-            y, y32 = engine.bpf2(f, b)
-            c64 = engine.xcorr(y, b)
-            res = {}
-            for mode in (0, 1):
-                engine.set_option("xcorr_mfma", mode)
-                c32 = engine.xcorr32(y32, b)
-                res[mode] = (c32, engine.pick_exact(c32, y, b))
-                fin = torch.isfinite(c32).all(dim=1)
-                assert float((c32.double() - c64).abs()[fin].max()) < 1e-5, (name, mode)          # well inside DELTA = 3e-5
-            assert torch.equal(torch.isnan(res[0][0]), torch.isnan(res[1][0])), name
-            d = (res[0][0] - res[1][0]).abs()
-            assert float(d[torch.isfinite(d)].max()) < 4e-6, name
-            for u, v in zip(res[0][1], res[1][1]):
-                assert torch.equal(u, v), name
-    finally:
-        engine.set_option("xcorr_mfma", 0)
-
-
-
 def test_sync_fast_large_batch_property(engine):
     """65 536 records: fast path == float64 path on every record (thr, npeaks, peaks)."""
     frames, band, pn = _workload(1024)
