@@ -68,6 +68,25 @@ struct es_ctx {
         }                                                                               \
     } while (0)
 
+#if defined(__HIPCC__)
+/* Inclusive prefix sum over the 64 lanes of a wave on the data-parallel primitives (row_shr 1, 2, 4, 8 inside the rows of 16, then the two
+ * row broadcasts): six dependent vector adds of a few cycles each, where six __shfl_up were six LDS-crossbar round trips (~100 cycles each).
+ * Lanes without a source keep the `old` operand, 0. */
+__device__ __forceinline__ uint32_t es_wave_incl_scan_u32(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     /* row_shr:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     /* row_bcast:15 into rows 1 and 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     /* row_bcast:31 into rows 2 and 3 */
+    return (uint32_t)v;
+}
+/* value of lane `src` (wave-uniform) in every lane: v_readlane instead of a ds_bpermute round trip */
+__device__ __forceinline__ int es_wave_read_lane(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+#endif
+
 static inline int es_wide_lanes_max(const es_ctx*) { return 256; }   /* lanes of the largest block of es_scl_wide.hip: the slab is sized in such blocks */
 /* kernels exist for power-of-two list sizes; a context created for list_size_max serves every size up to the next one */
 static inline int es_list_cap(int lmax) { int c = 1; while (c < lmax) c <<= 1; return c; }

@@ -196,9 +196,7 @@ __device__ uint32_t wave_select_key32(uint32_t (*hist)[256], const uint32_t (&kx
         #pragma unroll
         for (int b = 0; b < 4; ++b) h[b] = hist[0][4 * lane + b] + hist[1][4 * lane + b] + hist[2][4 * lane + b] + hist[3][4 * lane + b];
         const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
-        uint32_t incl = s4;
-        #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        const uint32_t incl = es_wave_incl_scan_u32(s4);
         const uint32_t excl = incl - s4;
         const bool hit = ((int)excl <= kk) && (kk < (int)incl);
         int bin = 0, nk = 0;
@@ -212,7 +210,7 @@ __device__ uint32_t wave_select_key32(uint32_t (*hist)[256], const uint32_t (&kx
         }
         const unsigned long long m = __ballot(hit);
         const int src = __ffsll((long long)m) - 1;
-        bin = __shfl(bin, src); kk = __shfl(nk, src);
+        bin = es_wave_read_lane(bin, src); kk = es_wave_read_lane(nk, src);
         prefix |= (uint32_t)bin << shift;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
     }

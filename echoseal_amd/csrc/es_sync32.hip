@@ -252,6 +252,70 @@ __device__ double corr64_at(const double* __restrict__ yr, int i, const double* 
     return num / (__builtin_sqrt(en) + 1e-12);
 }
 
+// The same value from a window of the record staged in LDS: w[x] = yr[c + x], x = 0 .. 80, c = i - i % XC_R, r = i - c.  Same operands in
+// the same order as corr64_at: bit-identical.
+// (w is an LDS pointer, not a generic one: through a generic pointer the compiler merges neighbouring doubles into 16-byte flat loads at
+// 8-byte alignment -- fine for global memory, a memory violation when the address resolves to LDS on this target: that is how the first
+// version of this routine aborted the queue.  With the address space known it emits 8-byte-aligned ds_read2_b64.)
+typedef __attribute__((address_space(3))) double xl_lds_double;
+__device__ __forceinline__ double corr64_window(const xl_lds_double* w, int r, const double* __restrict__ tpl)
+{
+    double num = 0.0;
+    #pragma unroll 9
+    for (int k = 0; k < ES_PRE_L; ++k) num = __builtin_fma(w[r + k], tpl[k], num);
+    double core = 0.0;
+    #pragma unroll 9
+    for (int m = 0; m < ES_PRE_L - XC_R + 1; ++m) core = core + w[XC_R - 1 + m] * w[XC_R - 1 + m];
+    double head = 0.0;
+    #pragma unroll 9
+    for (int u = 0; u < XC_R - 1; ++u) { const int j = XC_R - 2 - u; const double v = w[j]; if (j >= r) head = head + v * v; }
+    double tail = 0.0;
+    #pragma unroll 9
+    for (int u = 0; u < XC_R - 1; ++u) {
+        const int j = ES_PRE_L + u, last = r + ES_PRE_L - 1;
+        const double v = w[j <= last ? j : last];
+        if (j <= last) tail = tail + v * v;
+    }
+    const double en = (head + core) + tail;
+    return num / (__builtin_sqrt(en) + 1e-12);
+}
+
+// Exact correlations of `cnt` lags, lag_of(w) wave-uniform, w = 0 .. cnt-1, handed to out(w, value) in the lane w % XL_G.  The ~81 float64
+// samples a value reads (its own 63 and the rest of its 19-lag energy chunk) are fetched by the WHOLE wave -- two coalesced loads per value,
+// XL_G values' loads in flight together, one trip to memory per group -- into 4 KB of LDS (`stage`: the picker's histogram copies, dead
+// whenever this runs), and the value is then formed from LDS by one lane.  Before, each lane walked its value's samples through global
+// loads of its own: ~16 dependent trips to a row that no cache holds (0.4 ms of the fused kernel's 1.0 ms per 65 536 windows, by ablation).
+constexpr int XL_G = 6, XL_W = ES_PRE_L + XC_R - 1, XL_STRIDE = 84;    // 81 samples per window; 6 x 84 doubles = 4 032 B
+template <typename FL, typename FO>
+__device__ __forceinline__ void corr64_list(double* stage, int cnt, const double* __restrict__ yr, int n, const double* __restrict__ tpl, int lane, FL lag_of, FO out)
+{
+    static_assert(XL_G * XL_STRIDE * 8 <= 4096 && XL_W <= XL_STRIDE && XL_W - 64 <= 64, "stage area");
+    const int last = n + ES_PRE_L - 2;                                  // last sample of the record (n lags of ES_PRE_L taps)
+    xl_lds_double* const st = (xl_lds_double*)stage;                    // (`stage` is LDS: see corr64_window)
+    for (int g0 = 0; g0 < cnt; g0 += XL_G) {
+        const int ng = cnt - g0 < XL_G ? cnt - g0 : XL_G;
+        double v0[XL_G], v1[XL_G];
+        int rr = 0;
+        #pragma unroll
+        for (int w = 0; w < XL_G; ++w) {
+            const int i = lag_of(g0 + (w < ng ? w : 0));
+            const int c0 = i - i % XC_R;
+            if (w == lane) rr = i - c0;
+            const int a0 = c0 + lane, a1 = c0 + 64 + (lane < XL_W - 64 ? lane : 0);
+            v0[w] = yr[a0 <= last ? a0 : last];
+            v1[w] = yr[a1 <= last ? a1 : last];
+        }
+        #pragma unroll
+        for (int w = 0; w < XL_G; ++w) {
+            st[w * XL_STRIDE + lane] = v0[w];
+            if (lane < XL_W - 64) st[w * XL_STRIDE + 64 + lane] = v1[w];
+        }
+        wave_fence_lds();
+        if (lane < ng) out(g0 + lane, corr64_window(st + lane * XL_STRIDE, rr, tpl));
+        wave_fence_lds();
+    }
+}
+
 // ------------------------------------------------------------------------------------ pick (exact)
 constexpr int PX_MAXN = 4096;
 
@@ -317,9 +381,7 @@ __device__ uint32_t pw_select(PwFixed& S, int n, int k, int lane, F key)
             h[b] = t;
         }
         const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
-        uint32_t incl = s4;
-        #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        const uint32_t incl = es_wave_incl_scan_u32(s4);
         const uint32_t excl = incl - s4;
         const bool hit = ((int)excl <= kk) && (kk < (int)incl);
         int bin = 0, nk = 0;
@@ -333,7 +395,7 @@ __device__ uint32_t pw_select(PwFixed& S, int n, int k, int lane, F key)
         }
         const unsigned long long m = __ballot(hit);
         const int src = __ffsll((long long)m) - 1;
-        bin = __shfl(bin, src); kk = __shfl(nk, src);
+        bin = es_wave_read_lane(bin, src); kk = es_wave_read_lane(nk, src);
         prefix |= (uint32_t)bin << shift;
         wave_fence_lds();
     }
@@ -457,9 +519,7 @@ __device__ double pw_select64(PwFixed& S, int n, int k, int lane, F val)
             h[b] = t;
         }
         const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
-        uint32_t incl = s4;
-        #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        const uint32_t incl = es_wave_incl_scan_u32(s4);
         const uint32_t excl = incl - s4;
         const bool hit = ((int)excl <= kk) && (kk < (int)incl);
         int bin = 0, nk = 0;
@@ -473,7 +533,7 @@ __device__ double pw_select64(PwFixed& S, int n, int k, int lane, F val)
         }
         const unsigned long long m = __ballot(hit);
         const int src = __ffsll((long long)m) - 1;
-        bin = __shfl(bin, src); kk = __shfl(nk, src);
+        bin = es_wave_read_lane(bin, src); kk = es_wave_read_lane(nk, src);
         prefix |= (uint64_t)(uint32_t)bin << shift;
         wave_fence_lds();
     }
@@ -616,9 +676,7 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
         h[b] = t;
     }
     const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
-    uint32_t incl = s4;
-    #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    const uint32_t incl = es_wave_incl_scan_u32(s4);
     {
         uint32_t e = incl - s4;
         #pragma unroll
@@ -632,7 +690,7 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
         #pragma unroll
         for (int b = 0; b < 4; ++b) { if ((int)e <= k && k < (int)(e + h[b])) mine = 4 * lane + b; e += h[b]; }
         const unsigned long long m = __ballot(mine >= 0);
-        return __shfl(mine, __ffsll((long long)m) - 1);
+        return es_wave_read_lane(mine, __ffsll((long long)m) - 1);
     };
     const int bl = bin_of_rank(k_lo), bh = (k_hi == k_lo) ? bl : bin_of_rank(k_hi);
 
@@ -672,46 +730,52 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
         bt = bt < 0 ? 0 : (bt > 255 ? 255 : bt);
         any_cross = cum[256] - cum[bt] > 0;
     }
+    double* const stage = reinterpret_cast<double*>(&S.hist[0][0]);    // the histogram copies are dead from here on (a later select rebuilds them): corr64_list's windows
+    auto lane_f64 = [](double v, int src) {                             // v of lane `src` (wave-uniform)
+        const uint64_t u = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = (uint32_t)es_wave_read_lane((int)(uint32_t)u, src), hi = (uint32_t)es_wave_read_lane((int)(uint32_t)(u >> 32), src);
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    };
     for (int base = 0; any_cross && base < n && !overflow; base += 64) {
         const int i = base + lane;
         const bool cand = (i < n) && ((double)c[i] >= thr - DELTA);
-        unsigned long long m = __ballot(cand);
+        const unsigned long long m = __ballot(cand);
         if (!m) continue;
-        const double cv_mine = cand ? corr64_at(yr, i, tpl) : 0.0;      // all candidates of the chunk at once
-        while (m && !overflow) {
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int ci = base + bit;
-            const double cv = __shfl(cv_mine, bit);
-            if (cv < thr) continue;
+        const int nc = __popcll(m);
+        auto nth = [&](int w) { unsigned long long t = m; for (int q = 0; q < w; ++q) t &= t - 1; return base + (int)__ffsll((long long)t) - 1; };   // lag of the chunk's w-th candidate
+        // one candidate: exact value cv at lag ci -> a peak unless a bigger value sits within +-min_distance
+        auto settle = [&](int ci, double cv) {
+            if (cv < thr) return;
             int lo = ci - min_distance; if (lo < 0) lo = 0;
             int hi = ci + min_distance + 1; if (hi > n) hi = n;
-            bool bigger = false;
             int namb = 0;
-            for (int j0 = lo; j0 < hi && !bigger; j0 += 64) {
+            for (int j0 = lo; j0 < hi; j0 += 64) {
                 const int j = j0 + lane;
                 const bool in = j < hi;
                 const double s32 = in ? (double)c[j] : 0.0;
                 const bool big = in && s32 > cv + DELTA;
                 const bool amb = in && !big && s32 >= cv - DELTA && j != ci;   // rival within reach: settle exactly
-                if (__ballot(big)) { bigger = true; break; }
+                if (__ballot(big)) return;
                 const unsigned long long ma = __ballot(amb);
                 const int pos = namb + lanes_below(ma);
                 if (amb && pos < 64) S.list[pos] = j;
                 namb += __popcll(ma);
             }
-            if (bigger) continue;
-            if (namb > 64) { overflow = true; break; }
+            if (namb > 64) { overflow = true; return; }
             if (namb > 0) {
                 wave_fence_lds();
-                const bool have = lane < namb;
-                const double jv = have ? corr64_at(yr, S.list[lane], tpl) : 0.0;
-                const bool beats = have && jv > cv;
-                wave_fence_lds();
-                if (__ballot(beats)) continue;
+                bool beats = false;
+                corr64_list(stage, namb, yr, n, tpl, lane, [&](int w) { return S.list[w]; }, [&](int, double jv) { beats |= jv > cv; });
+                if (__ballot(beats)) return;
             }
             if (lane == 0 && total < ES_MAX_PEAKS) fo.peaks[rec * ES_MAX_PEAKS + total] = ci;
             ++total;
+        };
+        for (int g0 = 0; g0 < nc && !overflow; g0 += XL_G) {            // the chunk's candidates, XL_G exact values at a time (value of candidate g0 + w in lane w)
+            const int ng = nc - g0 < XL_G ? nc - g0 : XL_G;
+            double cvg = 0.0;
+            corr64_list(stage, ng, yr, n, tpl, lane, [&](int w) { return nth(g0 + w); }, [&](int, double v) { cvg = v; });
+            for (int w = 0; w < ng && !overflow; ++w) settle(nth(g0 + w), lane_f64(cvg, w));
         }
     }
     if (overflow) { flag_out(4); return; }
@@ -725,7 +789,7 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
             #pragma unroll
             for (int b = 0; b < 4; ++b) if ((int)(cum[256] - cum[4 * lane + b]) >= kmax) mine = 4 * lane + b;
             const unsigned long long m = __ballot(mine >= 0);
-            const int bstar = __shfl(mine, 63 - (int)__builtin_clzll(m));      // bin 0 always qualifies (n >= kmax)
+            const int bstar = es_wave_read_lane(mine, 63 - (int)__builtin_clzll(m));      // bin 0 always qualifies (n >= kmax)
             lo = (bstar == 0) ? -1e300 : (-1.0 + bstar * BINW) - 2.0 * DELTA - 1e-6;
         } else {
             const float t5 = key_f32(pw_select(S, n, n - kmax, lane, [&](int i) { return f32_key(c[i]); }));
@@ -742,7 +806,7 @@ __device__ void sync_pick_row(PwFixed& S, float* c, int n, const double* yr, con
         }
         if (nb > PW_CAP) { flag_out(5); return; }
         wave_fence_lds();
-        for (int idx = lane; idx < nb; idx += 64) S.val[idx] = corr64_at(yr, S.list[idx], tpl);
+        corr64_list(stage, nb, yr, n, tpl, lane, [&](int w) { return S.list[w]; }, [&](int w, double v) { S.val[w] = v; });
         wave_fence_lds();
         for (int idx = lane; idx < nb; idx += 64) {
             const double v = S.val[idx]; const int ii = S.list[idx];
