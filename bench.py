@@ -36,9 +36,10 @@ Extra objects:
   roofline      es_xcorr32_kernel<17,2048> -- the kernel north_star grades against the HBM roofline -- in the timed c3_unfused leg:
                 algorithmic bytes per launch (16 136 B per window, SURVEY.md section 8d) / mean launch duration against 8 TB/s;
                 `traffic` from the committed PMC passes.  NOT on the headline path (the product's sync is the fused kernel): labelled so.
-  roofline_fused  the fused sync kernel inside the timed headline steps (8 192 + 150 B per window): LDS- and float64-bound.
+  roofline_fused  the fused sync kernel (8 192 + 150 B per window), timed as a stand-alone launch (beside the list decoders of other lanes its
+                events span their time): LDS- and float64-bound.
   roofline_scl  the kernel that dominates the time (list decoder, ~88 % of a step), at the HEADLINE's own rate: vector instructions,
-                float64 instructions and HBM-side bytes per frame from the committed PMC passes (profiles/r03_scl_pmc.json).
+                float64 instructions and HBM-side bytes per frame from the committed PMC passes (profiles/r04_scl_pmc.json).
   cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") timed on this host on a bounded sample of the headline's
                 windows (rank 0, N = 1 only).
 """
@@ -364,11 +365,12 @@ def run_rank(a) -> None:
         dtu, x_ms, stage_u, (pk2, npk2, payload2, ok2) = c3_seq(False, nu)
         same = bool(torch.equal(pk_s, pk2) and torch.equal(npk_s, npk2) and torch.equal(payload_s, payload2) and torch.equal(ok_s, ok2))
         ach = XCORR_BYTES_PER_WINDOW * Bw / (x_ms * 1e-3) / 1e9
-        pmc = (_profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch", {})
+        pmc_file = next((f for f in ("r04_xcorr32_pmc_traffic.json", "r02_xcorr32_pmc_traffic.json") if _profile_json(f)), None)
+        pmc = (_profile_json(pmc_file) or {}).get("c3_launch", {}) if pmc_file else {}
         roof = {"kernel": "es_xcorr32_kernel<17,2048> (es_xcorr32_batch: the stand-alone correlation kernel north_star grades against HBM)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": pmc.get("hbm_bytes_per_launch") if Bw == 65536 else None,
-                "traffic_source": "rocprofv3 --pmc passes committed as profiles/r02_xcorr32_pmc_traffic.json (same launch shape; not re-measured by this run)",
+                "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed as profiles/{pmc_file} (same kernel, same launch shape; not re-measured by this run)",
                 "launch_ms": x_ms, "algorithmic_bytes_per_launch": XCORR_BYTES_PER_WINDOW * Bw,
                 "on_headline_path": False,
                 "where": f"HIP events around the launch inside the timed c3_unfused leg ({nu} steps); the headline's sync is the fused kernel "
@@ -566,7 +568,8 @@ def run_rank(a) -> None:
         out_legs["c5"] = c5_leg(eng, a, torch, np, WL)
 
     if rank == 0:
-        achf = FUSED_BYTES_PER_WINDOW * Bw / (fused_ms * 1e-3) / 1e9
+        fused_alone_ms = stage_ms["sync_fused"]                      # the launch alone (one sequential step, HIP events around it)
+        achf = FUSED_BYTES_PER_WINDOW * Bw / (fused_alone_ms * 1e-3) / 1e9
         out = {
             "metric": "watermark frames/sec decoded (sync+LLR+SCL-8) @ 48 kHz",
             "value": total * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
@@ -592,11 +595,14 @@ def run_rank(a) -> None:
         }
         roof_fused = {"kernel": "es_xcorr32_kernel<17,2048,FUSED> (es_sync_fused_batch: screen row kept in LDS, threshold and peaks settled in the same kernel)",
                       "bound": "hbm", "achieved": achf, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achf / HBM_PEAK_GBS,
-                      "traffic": ((_profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch_fused", {}).get("hbm_bytes_per_launch") if Bw == 65536 else None),
-                      "launch_ms": fused_ms, "algorithmic_bytes_per_launch": FUSED_BYTES_PER_WINDOW * Bw, "on_headline_path": True,
+                      "traffic": ((_profile_json("r04_xcorr32_pmc_traffic.json") or _profile_json("r02_xcorr32_pmc_traffic.json") or {}).get("c3_launch_fused", {}).get("hbm_bytes_per_launch") if Bw == 65536 else None),
+                      "launch_ms": fused_alone_ms, "launch_ms_inside_the_timed_steps": fused_ms,
+                      "algorithmic_bytes_per_launch": FUSED_BYTES_PER_WINDOW * Bw, "on_headline_path": True,
                       "note": "8 192 B of samples in + <= 150 B out per window (SURVEY 8d fused figure); bound by LDS passes and float64 re-evaluations, not by HBM -- "
                               "it exists to take 2 x 7 944 B per window of screen traffic and two launches away",
-                      "where": f"HIP events around the launch inside the timed headline steps ({a.steps} steps, beside the other lane's list decoder)"}
+                      "where": "`launch_ms` (and `achieved` / `frac`): HIP events around the launch in one sequential step, nothing beside it; "
+                               f"`launch_ms_inside_the_timed_steps`: the same events inside the timed headline steps ({a.steps} steps), where the launch is queued beside "
+                               "other lanes' list decoders and the events span their time too -- reported, not used"}
         if roof is not None:
             out["roofline"] = roof
             out["roofline_fused"] = roof_fused
@@ -616,7 +622,8 @@ def scl_roofline(head_fps, c4_fps, L, listed_share=1.0):
     """roofline_scl at the headline's own per-GPU rate, from the committed counter passes of es_scl_wide_kernel<64,8>.  Only the frames that
     go through the list loop cost what the counters say (the others are settled by the hard-decision shortcut, in a kernel of its own)."""
     all_fps, head_fps = head_fps, head_fps * listed_share
-    pmc = _profile_json("r03_scl_pmc.json")
+    pmc_name = next((f for f in ("r04_scl_pmc.json", "r03_scl_pmc.json") if _profile_json(f)), None)
+    pmc = _profile_json(pmc_name) if pmc_name else None
     if not pmc or L != 8:
         return None
     pf = pmc["per_frame"]
@@ -633,13 +640,15 @@ def scl_roofline(head_fps, c4_fps, L, listed_share=1.0):
            "valu_wave_instructions_per_frame": vi, "fp64_wave_instructions_per_frame": f64,
            "fp64_pipe_frac": (f64 * 4.0 + pf.get("trans_f64_instructions", 0) * 16.0) * head_fps / (N_SIMD * CLOCK_GHZ * 1e9),
            "issue_slot_frac_mixed_ceiling": busy_cycles_per_frame * head_fps / (N_SIMD * CLOCK_GHZ * 1e9),
+           "frac_guide_ceiling": (f64 * 4.0 + pf.get("trans_f64_instructions", 0) * 16.0 + other * 2.0) * head_fps / (N_SIMD * CLOCK_GHZ * 1e9),
            "issue_cycles_charged": cyc,
            "traffic": pf.get("hbm_side_bytes"), "algorithmic_bytes_per_frame": SCL_BYTES_PER_FRAME,
            "traffic_note": "bytes per frame through the L2's memory side (FETCH_SIZE x 2 for the 128-byte read requests + WRITE_SIZE; Infinity-Cache hits are counted): "
                            "the tree levels kept in the scratch slab, not the 4.6 KB a frame brings and leaves",
-           "how": "per-frame counts from the rocprofv3 --pmc passes committed as profiles/r03_scl_pmc.json (same kernel, B = 65 536) x the headline's frames/s per GPU; "
+           "how": f"per-frame counts from the rocprofv3 --pmc passes committed as profiles/{pmc_name} (same kernel, B = 65 536) x the headline's frames/s per GPU; "
                   "`frac` charges every vector instruction 4 cycles (peak 78.6 TFLOP/s FP64 vector = one wave64 instruction per 4 cycles on each of 1 024 SIMDs at 2.4 GHz); "
-                  "`issue_slot_frac_mixed_ceiling` charges each class what tools/ub/ub_issue.hip measures at three waves per SIMD; `fp64_pipe_frac` counts only float64 arithmetic"}
+                  "`issue_slot_frac_mixed_ceiling` charges each class what tools/ub/ub_issue.hip measures at three waves per SIMD; `frac_guide_ceiling` charges float64 4, "
+                  "v_rcp_f64 16 and every other vector instruction the 2 cycles of MI355X_MICROARCH.md (the lowest of the three readings); `fp64_pipe_frac` counts only float64 arithmetic"}
     return out
 
 

@@ -29,26 +29,53 @@ int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_
 {
     if (capturing(st)) return ES_OK;                            // a captured graph orders its own nodes
     es_ctx::slab_use& u = ctx->slab[domain];
-    const bool same = shareable && u.shareable && u.shape == shape;
-    if (!same) {
-        // another slot geometry (or a kernel that indexes the slab by block): the outstanding launches on OTHER streams must have
-        // drained first.  No shipped pipeline does this (one context per stream); it is a host-side wait, not a silent overlap.
-        for (hipStream_t other : u.streams)
-            if (other != st) ES_HIP_CHECK(ctx, hipStreamSynchronize(other));
-        u.streams.clear();
+    for (size_t k = 0; k < u.users.size();) {
+        es_ctx::slab_use::user& w = u.users[k];
+        const bool compatible = shareable && w.shareable && w.shape == shape;
+        if (w.st != st && hipEventQuery(w.done) == hipSuccess) {               // that stream's last launch here has finished: forget it
+            (void)hipEventDestroy(w.done);
+            u.users[k] = u.users.back(); u.users.pop_back();
+            continue;
+        }
+        // another slot geometry (or a kernel that indexes the slab by block): this launch is ordered behind that user's last one ON THE DEVICE.
+        // (Also for an entry of `st` itself: normally a no-op, and right if the handle value belongs to a new stream by now.)
+        if (!compatible) ES_HIP_CHECK(ctx, hipStreamWaitEvent(st, w.done, 0));
+        ++k;
     }
-    u.shape = shape; u.shareable = shareable;
-    bool known = false;
-    for (hipStream_t other : u.streams) known = known || (other == st);
-    if (!known) u.streams.push_back(st);
     return ES_OK;
 }
 
-// A launch that draws its frames from a counter gets a counter of its own: launches of one context on several streams (or in several
-// captured graphs) never share one unless ES_CURSOR_RING of them are in flight at once.
-int es_cursor_next(es_ctx* ctx, int** cursor)
+int es_slab_leave(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_t st)
 {
-    *cursor = ctx->d_cursors + (ctx->cursor_next++ % ES_CURSOR_RING);
+    if (capturing(st)) return ES_OK;
+    es_ctx::slab_use& u = ctx->slab[domain];
+    es_ctx::slab_use::user* mine = nullptr;
+    for (es_ctx::slab_use::user& w : u.users) if (w.st == st) mine = &w;
+    if (!mine) {
+        hipEvent_t ev;
+        ES_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        u.users.push_back({st, ev, shape, shareable});
+        mine = &u.users.back();
+    }
+    mine->shape = shape; mine->shareable = shareable;
+    ES_HIP_CHECK(ctx, hipEventRecord(mine->done, st));
+    return ES_OK;
+}
+
+// A launch that draws its frames from a counter gets a counter of its own.  Eager launches rotate over the first ES_CURSOR_RING -
+// ES_CURSOR_CAPTURED counters (one is reused only after that many further launches of the context); a launch recorded into a stream
+// capture takes one of the last ES_CURSOR_CAPTURED for good -- its graph may be replayed at any time, beside any eager launch.
+int es_cursor_next(es_ctx* ctx, hipStream_t st, int** cursor)
+{
+    if (capturing(st)) {
+        if (ctx->cursor_captured >= ES_CURSOR_CAPTURED) {
+            ctx->err = "es_scl_batch: this context has recorded its 256 list-decoder launches with skip_if_hard_ok into stream captures; use another context";
+            return ES_ENOMEM;
+        }
+        *cursor = ctx->d_cursors + (ES_CURSOR_RING - 1 - ctx->cursor_captured++);
+        return ES_OK;
+    }
+    *cursor = ctx->d_cursors + (ctx->cursor_next++ % (ES_CURSOR_RING - ES_CURSOR_CAPTURED));
     return ES_OK;
 }
 
@@ -123,6 +150,7 @@ void es_destroy(es_ctx* ctx)
 {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
+    for (es_ctx::slab_use& u : ctx->slab) for (es_ctx::slab_use::user& w : u.users) (void)hipEventDestroy(w.done);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->d_data_pos) (void)hipFree(ctx->d_data_pos);
     if (ctx->d_exp_tab) (void)hipFree(ctx->d_exp_tab);

@@ -47,10 +47,14 @@ struct es_ctx {
     /* Who is using a scratch slab (es_slab_enter).  Domain 0 = d_scl_scratch (es_scl.hip, es_scl_multi.hip),
        domain 1 = d_wide_scratch (es_scl_wide.hip).  `shape`: how the launch cuts the slab into slots; launches of one shareable shape on
        several streams share the slab through its slot bitmap, anything else is ordered behind the outstanding launches. */
-    struct slab_use { int shape = -1; bool shareable = false; std::vector<hipStream_t> streams; };   /* streams that have launched with `shape` */
+    struct slab_use {
+        struct user { hipStream_t st; hipEvent_t done; int shape; bool shareable; };   /* a stream's LAST launch on this slab: recorded after it (es_slab_leave) */
+        std::vector<user> users;
+    };
     slab_use slab[2];
     int* d_cursors = nullptr;         /* frame counters of the lane-per-path list decoder's launches (skip_if_hard_ok): a ring, one per launch */
-    unsigned cursor_next = 0;
+    unsigned cursor_next = 0;         /* eager launches rotate over the first ES_CURSOR_RING - ES_CURSOR_CAPTURED counters */
+    unsigned cursor_captured = 0;     /* launches recorded into a stream capture keep a counter of their own for the life of the context (the graph may replay at any time) */
     bool pick_attr_set = false;       /* per-device kernel attributes already raised for this context's device */
     unsigned wide_attr_mask = 0;      /* bit per instantiation of the lane-per-path list decoder (its list capacity 1 .. 256) */
     /* tuning (es_set_option) */
@@ -91,18 +95,22 @@ static inline int es_wide_lanes_max(const es_ctx*) { return 256; }   /* lanes of
 /* kernels exist for power-of-two list sizes; a context created for list_size_max serves every size up to the next one */
 static inline int es_list_cap(int lmax) { int c = 1; while (c < lmax) c <<= 1; return c; }
 
-/* Slab ownership (es_api.hip): call es_slab_enter before a launch that uses a scratch slab.
- * Launches on ONE stream are ordered by the stream.  Launches of one shareable shape (the kernels that claim slots from the slab's
- * bitmap) on several streams run concurrently.  A launch of another shape -- or of a kernel that indexes the slab by block -- first
- * waits on the host (hipStreamSynchronize) for the other streams that launched with the previous shape.  No-op inside a stream capture. */
+/* Slab ownership (es_api.hip): es_slab_enter before a launch that uses a scratch slab, es_slab_leave right after it (same arguments).
+ * Launches on ONE stream are ordered by the stream.  Launches of one shareable shape (the kernels that claim slots from the slab's bitmap)
+ * on several streams run concurrently.  A launch of another shape -- or of a kernel that indexes the slab by block -- is ordered behind the
+ * last launch of every other user ON THE DEVICE (hipStreamWaitEvent on the event es_slab_leave recorded): the host never blocks, and no
+ * stream handle is used after its owner may have destroyed it (the events belong to the context).  Inside a stream capture both are no-ops:
+ * a captured graph orders its own nodes, and graphs of different slot geometry must not be replayed concurrently on one context (header). */
 int es_slab_enter(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_t st);
+int es_slab_leave(es_ctx* ctx, int domain, int shape, bool shareable, hipStream_t st);
 
 /* launchers implemented in the kernel translation units */
 size_t es_scl_scratch_bytes(const es_ctx* ctx);
 size_t es_scl_wide_scratch_bytes(const es_ctx* ctx, int* slots_out);
 size_t es_scl_multi_scratch_bytes(const es_ctx* ctx);
 #define ES_CURSOR_RING 1024
-int es_cursor_next(es_ctx* ctx, int** cursor);                   /* the next counter of the ring (es_api.hip) */
+#define ES_CURSOR_CAPTURED 256                                   /* of them: set aside for launches recorded into stream captures (never reused) */
+int es_cursor_next(es_ctx* ctx, hipStream_t st, int** cursor);   /* a frame counter for one launch on `st` (es_api.hip) */
 int es_launch_scl_multi(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L, int skip_if_hard_ok,
                         uint8_t* hard_info, uint8_t* hard_ok, uint8_t* cand_info, double* cand_metric,
                         uint8_t* cand_ok, int32_t* ncand, hipStream_t st);

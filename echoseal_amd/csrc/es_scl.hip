@@ -667,6 +667,7 @@ int launch_scl(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     { const int rc = es_slab_enter(ctx, 0, 0x100 | L, false, st); if (rc) return rc; }     // slab indexed by block: never shared between streams
     hipLaunchKernelGGL(es_scl_kernel<L>, dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
+    { const int rc = es_slab_leave(ctx, 0, 0x100 | L, false, st); if (rc) return rc; }
 #ifdef ES_SCL_STAMPS
     {   // diagnostic build only: print the per-segment cycle shares of the first frames
         unsigned long long h[65 * 8];

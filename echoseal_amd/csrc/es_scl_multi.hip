@@ -601,6 +601,7 @@ int launch_multi(es_ctx* ctx, const SclArgs& a0, int64_t B, hipStream_t st)
     { const int rc = es_slab_enter(ctx, 0, 0x200 | PP, true, st); if (rc) return rc; }      // slot stride depends on PP only
     hipLaunchKernelGGL((es_scl_multi_kernel<L, PP>), dim3((unsigned)blocks), dim3(64 * MWPB), 0, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
+    { const int rc = es_slab_leave(ctx, 0, 0x200 | PP, true, st); if (rc) return rc; }
     return ES_OK;
 }
 

@@ -1081,6 +1081,7 @@ int launch_wide(es_ctx* ctx, WideArgs a, int64_t B, hipStream_t st)
     { const int rc = es_slab_enter(ctx, 1, 0x300 | L, true, st); if (rc) return rc; }       // slot stride depends on the block's lanes only
     hipLaunchKernelGGL((es_scl_wide_kernel<L, LF, GK>), dim3((unsigned)blocks), dim3(L), lds, st, a);
     ES_HIP_CHECK(ctx, hipGetLastError());
+    { const int rc = es_slab_leave(ctx, 1, 0x300 | L, true, st); if (rc) return rc; }
     return ES_OK;
 }
 
@@ -1116,7 +1117,7 @@ int es_launch_scl_wide(es_ctx* ctx, const void* llr, int dtype, int64_t B, int L
     a.n_info = ctx->n_info; a.info_bytes = (ctx->n_info - 8 + 7) / 8;
     if (skip_if_hard_ok && ES_WIDE_COMPACT) {             // frames drawn from a counter: see the kernel (settled frames never ride along as idle lanes)
         if (B >= (1LL << 31) - (1LL << 24)) { ctx->err = "es_scl_batch: batch too large for one launch"; return ES_EINVAL; }   // (the counter runs past B by one draw per block)
-        const int rc = es_cursor_next(ctx, &a.cursor);
+        const int rc = es_cursor_next(ctx, st, &a.cursor);
         if (rc) return rc;
         ES_HIP_CHECK(ctx, hipMemsetAsync(a.cursor, 0, sizeof(int), st));
     }

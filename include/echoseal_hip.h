@@ -147,8 +147,11 @@ int es_front_batch(es_ctx* ctx, const void* frames_dev, int dtype, int64_t B, in
  * list_size_max <= 32 by es_set_option "scl_lane_slab" / "scl_lanes" = 1 -- set those before the first enqueue-only call as well.
  * Streams: the float64 workspace is shared by every call on the context (one stream at a time for the entry points that use it).  The list
  * decoder's slabs are guarded: es_scl_batch launches on one stream are ordered by the stream, launches of the same slot geometry on several
- * streams share the slab through its slot bitmap, and a launch of another geometry on another stream first waits on the host
- * (hipStreamSynchronize) for the streams that used the previous one.                                                                                                         */
+ * streams share the slab through its slot bitmap, and a launch of another geometry is ordered ON THE DEVICE behind the last launch of every
+ * other stream that used the slab (hipStreamWaitEvent on an event the context records after each launch: the host does not block, the call
+ * stays enqueue-only).  Stream capture: the guard is not part of a captured graph -- do not replay graphs of different slot geometry
+ * (different list capacities / kernel mappings) of ONE context concurrently; launches with skip_if_hard_ok recorded into a capture keep a
+ * frame counter of their own for the life of the context (at most 256 such launches per context, ES_ENOMEM beyond).                                 */
 int es_reserve(es_ctx* ctx, int64_t B_max, int T_max);
 
 /* Convenience: the three float64 calls above back to back (workspace owned by the context). */

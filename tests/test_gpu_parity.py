@@ -1257,3 +1257,37 @@ def test_contexts_on_two_devices():
         outs.append((r.cand_metric.cpu(), r.cand_info.cpu(), p[0].cpu(), p[1].cpu()))
     for u, v in zip(*outs):
         assert torch.equal(u, v)
+
+
+def test_slab_guard_orders_geometries_across_streams():
+    """One context, two streams, list-decoder launches of DIFFERENT slot geometry back to back (64-lane blocks of the short lists, 128-lane
+    blocks of a 128-path list, the several-frames-per-wave kernel on the other slab): es_slab_enter / es_slab_leave order them on the device
+    (hipStreamWaitEvent, no host wait), so every launch must return what it returns alone.  Without the guard the second launch carves the
+    slab into other slots while the first is still using it."""
+    from echoseal_amd.engine import RxEngine
+    eng = RxEngine(0, list_size_max=128)
+    rng = np.random.default_rng(31)
+    big = torch.from_numpy(np.clip(rng.normal(0, 3, (16384, 1024)), -12, 12).astype(np.float32)).to(eng.device)
+    small = big[:96].contiguous()
+    eng.set_option("scl_multi", 1); eng.set_option("scl_lanes", 1)
+    ref8 = eng.scl(big, list_size=8, skip_if_hard_ok=False)
+    ref128 = eng.scl(small, list_size=128, skip_if_hard_ok=False)
+    eng.set_option("scl_lanes", 4)
+    ref_m = eng.scl(big[:4096].contiguous(), list_size=8, skip_if_hard_ok=False)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(eng.device), torch.cuda.Stream(eng.device)
+    for _ in range(3):
+        eng.set_option("scl_lanes", 1)
+        with torch.cuda.stream(sa):
+            a = eng.scl(big, list_size=8, skip_if_hard_ok=False)            # ~5 ms of 64-lane blocks on the lane-per-path slab
+        with torch.cuda.stream(sb):
+            b = eng.scl(small, list_size=128, skip_if_hard_ok=False)        # 128-lane blocks on the same slab, another stream, at once
+        with torch.cuda.stream(sa):
+            c = eng.scl(big, list_size=8, skip_if_hard_ok=False)            # and back
+        eng.set_option("scl_lanes", 4)
+        with torch.cuda.stream(sb):
+            m = eng.scl(big[:4096].contiguous(), list_size=8, skip_if_hard_ok=False)
+        torch.cuda.synchronize()
+        for got, want in ((a, ref8), (b, ref128), (c, ref8), (m, ref_m)):
+            assert torch.equal(got.cand_info, want.cand_info) and torch.equal(got.cand_metric, want.cand_metric) and torch.equal(got.ncand, want.ncand)
+    eng.set_option("scl_multi", -1); eng.set_option("scl_lanes", 0)

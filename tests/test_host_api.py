@@ -174,3 +174,21 @@ def test_undecoded_records_raise_not_pass_silently():
         select_payload(res, 1)
     res.ncand[1] = 8
     assert res.check() is res
+
+
+def test_tools_scripts_at_least_parse():
+    """tools/ holds measurement scripts that only run on the GPU box; here: every Python one compiles, every shell one passes `bash -n`, and
+    none refers to a file of this repository that does not exist (the round-3 tree kept tools for deleted experiments)."""
+    import py_compile
+    import subprocess
+    tools = os.path.join(ROOT, "tools")
+    for dirpath, _, files in os.walk(tools):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                py_compile.compile(path, doraise=True)
+            elif f.endswith(".sh"):
+                assert subprocess.run(["bash", "-n", path]).returncode == 0, path
+            if f.endswith((".py", ".sh")):
+                for ref in re.findall(r"tools/[\w/]+\.(?:py|sh|hip)", open(path).read()):
+                    assert os.path.exists(os.path.join(ROOT, ref)), f"{path} refers to {ref}"
