@@ -79,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--windows", type=int, default=65536, help="C3 windows per GPU per step (BASELINE config 3 = 65 536)")
     ap.add_argument("--list-size", type=int, default=8)
     ap.add_argument("--legs", default="auto", help="comma list of c2,c2_lanes,c3_unfused,c3_pcie,c4,c5 (auto: all at N = 1, c2 + c4 at N > 1; none: headline only)")
-    ap.add_argument("--big-lanes", type=int, default=4, help="pipeline lanes of the headline and of the c4 leg (launches of 65 536 records): up to 8")
+    ap.add_argument("--big-lanes", type=int, default=8, help="pipeline lanes of the headline and of the c4 leg (launches of 65 536 records): up to 8")
     ap.add_argument("--frames", type=int, default=1024, help="frame records per batch of the c2 legs (C2 = 1024)")
     ap.add_argument("--c2-steps", type=int, default=480)
     ap.add_argument("--group", type=int, default=16, help="c2: batches per list-decoder launch of the grouped pipeline")
