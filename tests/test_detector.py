@@ -34,6 +34,22 @@ def test_accept_rules_follow_reference():
     assert v(good) is True and v(bytes(bad)) is False and v(_blob(det, 9)) is False
 
 
+def test_hop_schedule_is_memoised_per_detector_only():
+    """choose_band(key, ctr) is memoised for the life of ONE detector (the counter search asks for the same few hundred counters clip after
+    clip); nothing keyed by the secret hop key survives in module state (round 3 kept a process-wide lru_cache of (key, ctr))."""
+    import echoseal_amd.utils as U
+    det = WatermarkDetector(KEY, list_size=8)
+    for c in (0, 1, 5, 255, 1024, 70000):
+        assert det._hop.band(c) == U.choose_band(KEY, c) and det._hop.index(c) == U.band_index(KEY, c)
+    assert set(det._hop._memo) == {0, 1, 5, 255, 1024, 70000}
+    assert not any(hasattr(getattr(U, n), "cache_info") for n in dir(U))          # no functools cache anywhere in the module
+    small = U.BandHop(KEY, limit=4)
+    for c in range(10):
+        small.index(c)
+    assert len(small._memo) <= 4
+    assert [U.band_index(b"\xAA" * 32, c) for c in range(16)] == [1, 3, 0, 2, 2, 1, 0, 3, 0, 2, 0, 1, 3, 0, 1, 3]   # SURVEY appendix A
+
+
 def test_constructor_contract():
     with pytest.raises(ValueError):
         WatermarkDetector(b"k" * 31)
