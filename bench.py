@@ -26,6 +26,8 @@ Further driver-timed legs in the same JSON line (`legs`), each bracketed by barr
             results; `roofline` is the stand-alone correlation kernel INSIDE this leg (HIP events on its launch stream).
   c3_pcie   the headline with every step's samples copied from pinned host memory over PCIe (copy stream, overlapped): the rate when the
             boundary hands over host buffers.  Reported beside the headline, never as `value`.
+  c3_sustained  the headline's steps for ~3 s on end (--sustained-steps, default 150) instead of 20: the rate the chip holds once clocks and
+            temperatures have settled, beside the 0.4 s burst the contract's K = 20 times.
   c4        BASELINE config 4, strong scaling: 2^20 frames in total, ctr 0 .. 2^20-1, sharded contiguously over the N ranks; rank 0
             derives the whole schedule (153 B per counter = 160 MB) and broadcasts it; a checksum over (frame index, payload, ok,
             sync offset) summed over ranks is the same number at every N.
@@ -78,13 +80,14 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=65536, help="C3 windows per GPU per step (BASELINE config 3 = 65 536)")
     ap.add_argument("--list-size", type=int, default=8)
-    ap.add_argument("--legs", default="auto", help="comma list of c2,c2_lanes,c3_unfused,c3_pcie,c4,c5 (auto: all at N = 1, c2 + c4 at N > 1; none: headline only)")
+    ap.add_argument("--legs", default="auto", help="comma list of c2,c2_lanes,c3_unfused,c3_pcie,c3_sustained,c4,c5 (auto: all at N = 1, c2 + c4 at N > 1; none: headline only)")
+    ap.add_argument("--sustained-steps", type=int, default=150, help="steps of the c3_sustained leg (~19 ms each)")
     ap.add_argument("--big-lanes", type=int, default=8, help="pipeline lanes of the headline and of the c4 leg (launches of 65 536 records): up to 8")
     ap.add_argument("--frames", type=int, default=1024, help="frame records per batch of the c2 legs (C2 = 1024)")
     ap.add_argument("--c2-steps", type=int, default=480)
     ap.add_argument("--group", type=int, default=16, help="c2: batches per list-decoder launch of the grouped pipeline")
     ap.add_argument("--front-lanes", type=int, default=4, help="c2: front-end streams of the grouped pipeline")
-    ap.add_argument("--scl-streams", type=int, default=2, help="c2: list-decoder streams of the grouped pipeline")
+    ap.add_argument("--scl-streams", type=int, default=3, help="c2: list-decoder streams of the grouped pipeline")
     ap.add_argument("--c4-frames", type=int, default=1 << 20, help="total frames of the strong-scaling leg (all ranks together)")
     ap.add_argument("--c4-chunk", type=int, default=65536)
     ap.add_argument("--c5-frames", type=int, default=16384)
@@ -245,7 +248,7 @@ def run_rank(a) -> None:
     from echoseal_amd.engine import DecodePipeline, RxEngine, pipeline_streams
     from echoseal_amd import workloads as WL
 
-    legs = {"auto": ["c2", "c2_lanes", "c3_unfused", "c3_pcie", "c4", "c5"] if world == 1 else ["c2", "c4"], "none": []}.get(a.legs, a.legs.split(","))
+    legs = {"auto": ["c2", "c2_lanes", "c3_unfused", "c3_pcie", "c3_sustained", "c4", "c5"] if world == 1 else ["c2", "c4"], "none": []}.get(a.legs, a.legs.split(","))
     L = a.list_size
     eng = RxEngine(local, list_size_max=max(16, L))
     tx = WatermarkEmbedder(KEY)
@@ -417,6 +420,24 @@ def run_rank(a) -> None:
                                "value": world * Bw * npc / dtp, "unit": "frames/s", "scaling": "weak", "steps": npc, "ms_per_step": 1e3 * dtp / npc,
                                "host_to_device_GBps_needed": win.numel() * 4 * npc / dtp / 1e9, "results_identical_to_the_headline": same_p}
         del host, bufs, syp, sclp
+    # ============================================================ leg c3_sustained: the headline's steps for seconds on end
+    if "c3_sustained" in legs:
+        ns = max(1, a.sustained_steps)
+        torch.cuda.synchronize()
+        gc.collect(); gc.disable()
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(ns):
+            sys_, scls_ = c3_step()
+        barrier()
+        dts = max_over_ranks(time.perf_counter() - ts)
+        gc.enable()
+        same_s = bool(torch.equal(sys_.peaks, pk) and torch.equal(scls_.selected[0], payload3))
+        out_legs["c3_sustained"] = {"workload": f"the headline's step (same windows, same {a.big_lanes} lanes) {ns} times in a row",
+                                    "value": world * Bw * ns / dts, "unit": "frames/s", "scaling": "weak", "steps": ns, "seconds": dts,
+                                    "ms_per_step": 1e3 * dts / ns, "ratio_to_the_headline": (world * Bw * ns / dts) / (total * a.steps / dt),
+                                    "results_identical_to_the_headline": same_s}
+        del sys_, scls_
     del pk_s, npk_s, payload_s, ok_s, sy3, scl3, payload3, ok3, pk, npk
     win_h = band_h = pn_h = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
