@@ -5,14 +5,16 @@
 // pointers instead of path copies, trace-back instead of per-path bit arrays, Python's stable sort order).
 //
 // Where things live (lane p owns path p and slot p of every slot-indexed store):
-//   * LLR tree depths 1..7 (512..8 values per path): an L2 / Infinity-Cache resident scratch slab laid out
-//     [element][slot], so the lanes of a wave touch one contiguous row; a lane walks a node's elements serially.
-//   * depths 8 and 9 (4 + 2 values): LDS, [element][slot]; depth 10 (the leaf LLR): a register.
+//   * LLR tree depths 1..DL-1 (512..16 values per path): a scratch slab laid out [element][slot] (no cache holds it), so the lanes of a
+//     wave touch one contiguous row; a lane walks a node's elements serially.  DL = 7 in one-wave blocks, 8 in blocks of several waves.
+//     The g half of depth 1 (bits 512..) is never stored: llr[e + 512] +- llr[e], formed on the fly where it is consumed (ES_WIDE_L1R).
+//   * depths DL..9 (8 + 4 + 2 values at DL = 7): LDS, [element][slot]; depth 10 (the leaf LLR): a register.
 //   * slot pointers (which slot holds my data at depth d): one byte per depth packed in two 64-bit registers,
 //     partial-sum blocks of 1..16 bits in one 32-bit register (as in es_scl.hip), of 32 and 64 bits in LDS by
 //     slot, of 128 / 256 / 512 bits (read a few times per frame) in the slab.
-//   * a sort moves registers only: every path publishes (pointers, small partial sums, trace-back window, the
-//     softplus pair of the even sibling) to LDS, and the survivor of rank r -- lane r -- reads its parent's.
+//   * a sort moves registers only.  One-wave blocks: the survivor of rank r -- lane r -- fetches sorted element r and its parent's
+//     (pointers, small partial sums, trace-back window, softplus pair of the even sibling) straight from the registers of the lanes that
+//     hold them (ds_bpermute).  Blocks of several waves publish them to LDS and read the parent's after the sort's barriers.
 //   * trace-back by windows of 32 information bits (as in es_scl_multi.hip): a path carries the bits of the
 //     current window and the path it descended from at the window's start; a full window goes to the slab once.
 //
@@ -29,7 +31,7 @@
 //
 // SHORT lists (LF = 1..64 paths per frame): the block is one wave that carries 64/LF whole frames (8 at LF = 8); the sort network
 // stops at the frame's 2 LF candidates and every "barrier" is a wave fence.  All 64 lanes are busy at every tree depth, which the
-// lanes-share-a-path kernels (es_scl.hip, es_scl_multi.hip) cannot offer at the bottom of the tree: 155 k instead of 184 k / 224 k
+// lanes-share-a-path kernels (es_scl.hip, es_scl_multi.hip) cannot offer at the bottom of the tree: 126 k instead of 184 k / 224 k
 // vector instructions per frame at L = 8.  The price is latency: a wave carries its frames through the whole decode (~7 ms), so
 // es_scl_batch picks this mapping for large launches only (or es_set_option "scl_lanes" = 1: the grouped pipeline).
 //
