@@ -1291,3 +1291,41 @@ def test_slab_guard_orders_geometries_across_streams():
         for got, want in ((a, ref8), (b, ref128), (c, ref8), (m, ref_m)):
             assert torch.equal(got.cand_info, want.cand_info) and torch.equal(got.cand_metric, want.cand_metric) and torch.equal(got.ncand, want.ncand)
     eng.set_option("scl_multi", -1); eng.set_option("scl_lanes", 0)
+
+
+def test_captured_list_decode_keeps_its_frame_counter():
+    """A list-decoder launch with skip_if_hard_ok draws its frames from a per-launch counter.  Recorded into a stream capture it takes one of
+    the context's reserved counters for good (es_cursor_next), so a replay of the graph BESIDE eager launches of the same context -- which
+    rotate over the other counters -- decodes exactly what the eager launch decodes.  (Round 3 handed every launch the next counter of one
+    ring: a replay could meet an eager launch on the same counter.)"""
+    from echoseal_amd.engine import RxEngine
+    eng = RxEngine(0, list_size_max=8)
+    eng.set_option("scl_multi", 1); eng.set_option("scl_lanes", 1)          # the lane-per-path kernel: the one that draws frames
+    rng = np.random.default_rng(77)
+    info = torch.from_numpy(rng.integers(0, 256, (4096, 55), dtype=np.uint8)).to(eng.device)
+    code = eng.polar_encode(info).to(torch.float32)
+    clean = (2.0 * code - 1.0) * 6.0
+    noisy = torch.from_numpy(np.clip(rng.normal(0, 3, (4096, 1024)), -12, 12).astype(np.float32)).to(eng.device)
+    mix = torch.where(torch.from_numpy(rng.random(4096) < 0.5).to(eng.device)[:, None], noisy, clean).contiguous()   # half the frames pass the hard decision
+    ref = eng.scl(mix, list_size=8, skip_if_hard_ok=True)
+    other = eng.scl(noisy, list_size=8, skip_if_hard_ok=True)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream(eng.device)
+    with torch.cuda.stream(s):
+        eng.scl(mix, list_size=8, skip_if_hard_ok=True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = eng.scl(mix, list_size=8, skip_if_hard_ok=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(eng.device)
+    for _ in range(4):
+        g.replay()
+        with torch.cuda.stream(side):                                        # eager launches of the same context beside the replay
+            for _ in range(3):
+                o2 = eng.scl(noisy, list_size=8, skip_if_hard_ok=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out.ncand, ref.ncand) and torch.equal(out.cand_info, ref.cand_info) and torch.equal(out.cand_metric, ref.cand_metric)
+        assert torch.equal(o2.cand_info, other.cand_info) and torch.equal(o2.ncand, other.ncand)
+    assert int((ref.ncand == 0).sum()) > 1000 and int((ref.ncand == 8).sum()) > 1000
+    eng.set_option("scl_multi", -1); eng.set_option("scl_lanes", 0)
