@@ -6,7 +6,8 @@ cd "$(dirname "$0")/../echoseal_amd/csrc"
 name=$1; file=$2; flags=$3
 make -s >/dev/null
 obj=/tmp/variant_${name}_$(basename ${file%.hip}).o
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $flags -c $file -o $obj
+per_file=$(sed -n "s/^FLAGS_$(basename ${file%.hip}) := //p" Makefile)      # the Makefile's per-file flags (es_sync32: no SLP vectorisation)
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $per_file $flags -c $file -o $obj
 others=$(ls *.o | grep -v "^$(basename ${file%.hip}).o$")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libechoseal_hip_${name}.so $obj $others
 echo built ../libechoseal_hip_${name}.so
